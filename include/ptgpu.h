@@ -1,0 +1,178 @@
+/*
+ * ptgpu.h -- C ABI of the MI355X (gfx950) implementation of Esgrove/pathtracer's
+ * per-sample path-tracing hot path.
+ *
+ * The reference has no FFI/plugin layer: its boundary is the C++ class interface in
+ * namespace FW.  This header is the device boundary inserted *under*
+ * those classes: the host-side C++ mirror in pathtracer_amd/host/ (same class and
+ * method names as the reference) calls only these functions.  Each entry point cites
+ * the reference interface it replaces.
+ *
+ * Conventions: every function returns 0 on success or a negative PTGPU_E_* code and
+ * never throws; ptgpu_last_error() gives a thread-local message.  No callbacks into
+ * host code.  One context per device; a context is used from one host thread at a
+ * time.  Inputs are copied at scene creation: the caller keeps ownership of what it
+ * passes in.  Functions whose name ends in _dev take DEVICE pointers and only enqueue
+ * work on the context's stream (ptgpu_set_stream); the others take HOST pointers,
+ * copy, run and synchronise.
+ *
+ * All arithmetic is fp32 with no FMA contraction, in the reference's operation order,
+ * so closest-hit / any-hit results (id, t, u, v) are bit-identical to the CPU code.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTGPU_OK 0
+#define PTGPU_E_INVALID (-1)   /* bad argument / malformed scene (message says what) */
+#define PTGPU_E_HIP (-2)       /* a HIP runtime call failed */
+#define PTGPU_E_NODEVICE (-3)  /* no usable gfx950 device */
+#define PTGPU_E_UNSUPPORTED (-4)
+
+typedef struct ptgpu_context ptgpu_context;
+typedef struct ptgpu_scene ptgpu_scene;
+
+/* FlatNode exactly as the reference lays it out (src/BvhNode.hpp:67-113, sizeof == 64):
+ * depth-first pre-order array, left child = index + 1 (src/Bvh.cpp:70-96). Uploaded as-is. */
+typedef struct ptgpu_flatnode {
+    float bmin[3], bmax[3];
+    int32_t startIdx, endIdx; /* inclusive range into the triangle index list */
+    uint8_t leaf;
+    uint8_t _padleaf[3];
+    int32_t rightChild;
+    int32_t axis;
+    int32_t leftChild;
+    int32_t triangles;
+    int32_t pad0, pad1, pad2;
+} ptgpu_flatnode;
+
+/* FW MeshBase::Material fields the path reads (src/PathTraceRenderer.cpp:76-83,134,174-175,311;
+ * src/RayTracer.cpp:206). tex_* index ptgpu_scene_desc.textures, -1 = texture absent. */
+typedef struct ptgpu_material {
+    float diffuse[4];
+    float specular[3];
+    float glossiness;
+    int32_t tex_diffuse, tex_alpha, tex_normal, tex_specular;
+} ptgpu_material;
+
+/* 8-bit RGBA image; Image::getVec4f(x,y) == texel / 255 */
+typedef struct ptgpu_texture {
+    int32_t width, height;
+    const uint8_t* rgba; /* HOST pointer, width*height*4 bytes, row-major */
+} ptgpu_texture;
+
+/* AreaLight state (src/AreaLight.hpp:74-79) */
+typedef struct ptgpu_light {
+    float xform[16]; /* column-major Mat4f m_xform */
+    float size[2];   /* m_size (half extents) */
+    float E[3];      /* m_E */
+    float intensity; /* m_intensity */
+    float power;     /* m_power, as updatePower() leaves it (src/AreaLight.hpp:54-57) */
+} ptgpu_light;
+
+/* What tracePath reads from CameraControls per sample (src/PathTraceRenderer.cpp:244-291), computed once on the host */
+typedef struct ptgpu_camera {
+    float invP[16];       /* (fitToView * cameraToClip * worldToCamera).inverted(), column-major */
+    float forward[3];     /* getForward() */
+    float orient_col0[3]; /* getOrientation().getCol(0) */
+    float orient_col1[3]; /* getOrientation().getCol(1) */
+    float far_;           /* getFar() */
+} ptgpu_camera;
+
+/* The static tunables of PathTraceRenderer (src/PathTraceRenderer.cpp:15-28) and the per-render values of
+ * PathTracerContext (src/PathTraceRenderer.hpp:33-54), passed by value to the kernels. */
+typedef struct ptgpu_params {
+    int32_t width, height;
+    int32_t bounces;        /* m_bounces: <0 = Russian roulette after |bounces| */
+    int32_t num_aa_rays;    /* m_NumAaRays */
+    int32_t sobol_block;    /* m_sobolBlock */
+    int32_t bilinear;       /* m_bilinearFiltering */
+    int32_t normal_mapped;  /* m_normalMapped */
+    int32_t depth_of_field; /* m_depthOfField */
+    int32_t whitted;        /* m_whitted */
+    int32_t num_light_rays; /* m_numLightRays */
+    int32_t use_alpha;      /* RayTracer::useAlpha (src/RayTracer.hpp:39) */
+    uint32_t pass_seed;     /* stands in for the process-global seed counter at src/PathTraceRenderer.cpp:689-691 */
+    float aperture, attenuation, filter_width, focal_distance, intensity, termination_prob;
+} ptgpu_params;
+
+/* Scene as the host classes hold it: the caller's triangle vector flattened to arrays (one entry per
+ * RTTriangle, src/RTTriangle.hpp:23-33) and the BVH's public members (src/Bvh.hpp:36-43). */
+typedef struct ptgpu_scene_desc {
+    int32_t num_tris;
+    const float* pos;      /* [num_tris][3][3]  m_vertices[k].p */
+    const float* nrm;      /* [num_tris][3][3]  m_vertices[k].n */
+    const float* uv;       /* [num_tris][3][2]  m_vertices[k].t */
+    const int32_t* mat_id; /* [num_tris]        index of m_material in materials[] */
+    const float* woop;     /* [num_tris][3][4]  row r = (M(r,0), M(r,1), M(r,2), N[r]) of tri_data (src/RTTriangle.hpp:8-21) */
+    int32_t num_materials;
+    const ptgpu_material* materials;
+    int32_t num_textures;
+    const ptgpu_texture* textures;
+    int32_t num_nodes;
+    const ptgpu_flatnode* nodes; /* BVH::nodes */
+    int32_t list_size;
+    const int32_t* list;         /* BVH::list */
+} ptgpu_scene_desc;
+
+/* Same definition as the reference's counter: 1 ray = 1 raycast() call (src/RayTracer.cpp:192). node_visits and
+ * tri_tests count FlatNode::intersect and intersect_woop calls of the reference's traversal (src/RayTracer.cpp:197,203)
+ * and are only collected while ptgpu_enable_counters(ctx, 1) is in force (they cost time). */
+typedef struct ptgpu_counters {
+    uint64_t rays, node_visits, tri_tests;
+} ptgpu_counters;
+
+/* ---- context -------------------------------------------------------------------------------------------------- */
+int ptgpu_init(int device, ptgpu_context** out_ctx);
+int ptgpu_shutdown(ptgpu_context* ctx);
+const char* ptgpu_last_error(void);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream. */
+int ptgpu_set_stream(ptgpu_context* ctx, void* hip_stream);
+int ptgpu_sync(ptgpu_context* ctx);
+/* device memory for callers that have no allocator of their own (the C++ host classes) */
+int ptgpu_malloc(ptgpu_context* ctx, uint64_t bytes, void** out_dev);
+int ptgpu_free(ptgpu_context* ctx, void* dev);
+int ptgpu_memcpy_h2d(ptgpu_context* ctx, void* dev, const void* host, uint64_t bytes);
+int ptgpu_memcpy_d2h(ptgpu_context* ctx, void* host, const void* dev, uint64_t bytes);
+int ptgpu_memset(ptgpu_context* ctx, void* dev, int value, uint64_t bytes);
+
+/* replaces RayTracer::getRayCount / resetRayCounter (src/RayTracer.hpp:34-35) */
+int ptgpu_enable_counters(ptgpu_context* ctx, int on);
+int ptgpu_get_counters(ptgpu_context* ctx, ptgpu_counters* out);
+int ptgpu_reset_counters(ptgpu_context* ctx);
+
+/* ---- scene: replaces RayTracer::constructHierarchy's hand-over of triangles + BVH (src/RayTracer.cpp:167-172) and
+ * App::constructTracer's triangle array (src/App.cpp:826-838).  Validates the tree (ranges, child indices, depth <= 64 =
+ * the reference's traversal stack, src/RayTracer.cpp:190) and builds the device traversal layout. */
+int ptgpu_scene_create(ptgpu_context* ctx, const ptgpu_scene_desc* desc, ptgpu_scene** out_scene);
+int ptgpu_scene_destroy(ptgpu_scene* scene);
+/* bytes of device memory held by the scene: [0] interior nodes, [1] triangle records, [2] shading attributes, [3] textures */
+int ptgpu_scene_stats(const ptgpu_scene* scene, uint64_t out_bytes[4], int32_t* out_depth);
+
+/* ---- RayTracer::raycast(orig, dir, occlusion) (src/RayTracer.cpp:174-290), n rays per call.
+ * orig/dir: [n][3] floats (Vec3f arrays); the traced segment is [orig, orig+dir].  use_alpha = RayTracer::useAlpha.
+ * out_id: index into the caller's triangle vector or -1 (RaycastResult::tri == nullptr); out_t = FLT_MAX, u = v = 0 on a
+ * miss (src/RaycastResult.hpp:27).  Any out_* may be NULL.  occlusion != 0: any-hit early exit (src/RayTracer.cpp:235-238). */
+int ptgpu_raycast_batch(ptgpu_scene* scene, int use_alpha, const float* orig, const float* dir, int64_t n, int occlusion,
+                        int32_t* out_id, float* out_t, float* out_u, float* out_v);
+int ptgpu_raycast_batch_dev(ptgpu_scene* scene, int use_alpha, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
+                            int32_t* d_id, float* d_t, float* d_u, float* d_v);
+
+/* Ray generators of BASELINE config 2: pixel-centre primary rays unprojected through invP exactly as
+ * src/PathTraceRenderer.cpp:244-266 with the pixel->clip mapping of :716-717, and one shadow ray per primary hit built as
+ * :338-344 builds it (origin O + 1e-4 N with N the interpolated vertex normal, direction Pl - O un-normalised) towards the
+ * Sobol point of the light with index = ray index, dims 4 and 5 (src/AreaLight.cpp:75-81 without the RNG offset). */
+int ptgpu_gen_primary_dev(ptgpu_context* ctx, const ptgpu_camera* cam, int32_t width, int32_t height, float* d_orig, float* d_dir);
+int ptgpu_gen_shadow_dev(ptgpu_scene* scene, const ptgpu_light* light, int64_t n, const float* d_orig, const float* d_dir,
+                         const int32_t* d_id, const float* d_t, const float* d_u, const float* d_v,
+                         float* d_sh_orig, float* d_sh_dir, int32_t* d_sh_valid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

@@ -1,0 +1,243 @@
+"""ctypes binding of include/ptgpu.h (libptgpu.so, the gfx950 kernels behind a C ABI).
+
+This is plumbing for tests and bench.py; the product's host side is the C++ mirror of the
+reference's classes in pathtracer_amd/host/.  There is NO CPU fallback: if the library is
+missing or a call fails, PtgpuError is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptgpu.so")
+
+
+class PtgpuError(RuntimeError):
+    pass
+
+
+class FlatNode(C.Structure):  # reference src/BvhNode.hpp:67-113
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("startIdx", C.c_int32), ("endIdx", C.c_int32),
+                ("leaf", C.c_uint8), ("_padleaf", C.c_uint8 * 3), ("rightChild", C.c_int32), ("axis", C.c_int32),
+                ("leftChild", C.c_int32), ("triangles", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32),
+                ("pad2", C.c_int32)]
+
+
+FLATNODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("startIdx", "<i4"), ("endIdx", "<i4"),
+                           ("leaf", "u1"), ("_padleaf", "u1", 3), ("rightChild", "<i4"), ("axis", "<i4"),
+                           ("leftChild", "<i4"), ("triangles", "<i4"), ("pad0", "<i4"), ("pad1", "<i4"), ("pad2", "<i4")])
+assert C.sizeof(FlatNode) == 64 and FLATNODE_DTYPE.itemsize == 64
+
+
+class Material(C.Structure):
+    _fields_ = [("diffuse", C.c_float * 4), ("specular", C.c_float * 3), ("glossiness", C.c_float),
+                ("tex_diffuse", C.c_int32), ("tex_alpha", C.c_int32), ("tex_normal", C.c_int32), ("tex_specular", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", C.c_void_p)]
+
+
+class Light(C.Structure):  # reference src/AreaLight.hpp:74-79
+    _fields_ = [("xform", C.c_float * 16), ("size", C.c_float * 2), ("E", C.c_float * 3), ("intensity", C.c_float),
+                ("power", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("invP", C.c_float * 16), ("forward", C.c_float * 3), ("orient_col0", C.c_float * 3),
+                ("orient_col1", C.c_float * 3), ("far_", C.c_float)]
+
+
+class Params(C.Structure):  # reference src/PathTraceRenderer.cpp:15-28
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("num_aa_rays", C.c_int32),
+                ("sobol_block", C.c_int32), ("bilinear", C.c_int32), ("normal_mapped", C.c_int32),
+                ("depth_of_field", C.c_int32), ("whitted", C.c_int32), ("num_light_rays", C.c_int32),
+                ("use_alpha", C.c_int32), ("pass_seed", C.c_uint32), ("aperture", C.c_float), ("attenuation", C.c_float),
+                ("filter_width", C.c_float), ("focal_distance", C.c_float), ("intensity", C.c_float),
+                ("termination_prob", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("num_tris", C.c_int32), ("pos", C.c_void_p), ("nrm", C.c_void_p), ("uv", C.c_void_p),
+                ("mat_id", C.c_void_p), ("woop", C.c_void_p), ("num_materials", C.c_int32), ("materials", C.c_void_p),
+                ("num_textures", C.c_int32), ("textures", C.c_void_p), ("num_nodes", C.c_int32), ("nodes", C.c_void_p),
+                ("list_size", C.c_int32), ("list", C.c_void_p)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64)]
+
+
+# every symbol include/ptgpu.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = [
+    ("ptgpu_init", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("ptgpu_shutdown", C.c_int, [_P]),
+    ("ptgpu_last_error", C.c_char_p, []),
+    ("ptgpu_set_stream", C.c_int, [_P, _P]),
+    ("ptgpu_sync", C.c_int, [_P]),
+    ("ptgpu_malloc", C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    ("ptgpu_free", C.c_int, [_P, _P]),
+    ("ptgpu_memcpy_h2d", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("ptgpu_memcpy_d2h", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("ptgpu_memset", C.c_int, [_P, _P, C.c_int, C.c_uint64]),
+    ("ptgpu_enable_counters", C.c_int, [_P, C.c_int]),
+    ("ptgpu_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
+    ("ptgpu_reset_counters", C.c_int, [_P]),
+    ("ptgpu_scene_create", C.c_int, [_P, C.POINTER(SceneDesc), C.POINTER(_P)]),
+    ("ptgpu_scene_destroy", C.c_int, [_P]),
+    ("ptgpu_scene_stats", C.c_int, [_P, C.POINTER(C.c_uint64 * 4), C.POINTER(C.c_int32)]),
+    ("ptgpu_raycast_batch", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    ("ptgpu_raycast_batch_dev", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    ("ptgpu_gen_primary_dev", C.c_int, [_P, C.POINTER(Camera), C.c_int32, C.c_int32, _P, _P]),
+    ("ptgpu_gen_shadow_dev", C.c_int, [_P, C.POINTER(Light), C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+]
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """Load libptgpu.so and bind every declared symbol.  Raises PtgpuError if the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise PtgpuError("HIP extension %s is not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    lib = C.CDLL(path)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtgpuError("ptgpu error %d: %s" % (rc, load_library().ptgpu_last_error().decode()))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _P()
+        _check(self.lib.ptgpu_init(device, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.ptgpu_shutdown(self.handle)
+            self.handle = None
+
+    def set_stream(self, stream_ptr):
+        _check(self.lib.ptgpu_set_stream(self.handle, stream_ptr))
+
+    def sync(self):
+        _check(self.lib.ptgpu_sync(self.handle))
+
+    def malloc(self, nbytes):
+        p = _P()
+        _check(self.lib.ptgpu_malloc(self.handle, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, p):
+        _check(self.lib.ptgpu_free(self.handle, p))
+
+    def h2d(self, dev, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(self.lib.ptgpu_memcpy_h2d(self.handle, dev, arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, dev, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        _check(self.lib.ptgpu_memcpy_d2h(self.handle, out.ctypes.data, dev, out.nbytes))
+        return out
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        self.h2d(p, arr)
+        return p
+
+    def enable_counters(self, on):
+        _check(self.lib.ptgpu_enable_counters(self.handle, 1 if on else 0))
+
+    def reset_counters(self):
+        _check(self.lib.ptgpu_reset_counters(self.handle))
+
+    def counters(self):
+        c = Counters()
+        _check(self.lib.ptgpu_get_counters(self.handle, C.byref(c)))
+        return dict(rays=c.rays, node_visits=c.node_visits, tri_tests=c.tri_tests)
+
+    def gen_primary_dev(self, cam, width, height, d_orig, d_dir):
+        _check(self.lib.ptgpu_gen_primary_dev(self.handle, C.byref(cam), width, height, d_orig, d_dir))
+
+
+def make_scene_desc(sd):
+    """sd: dict with numpy arrays pos[n,3,3] nrm[n,3,3] uv[n,3,2] mat_id[n] woop[n,12] materials (list of Material)
+    textures (list of uint8 arrays [h,w,4]) nodes (FLATNODE_DTYPE array) list (int32).  Returns (SceneDesc, keepalive)."""
+    keep = {}
+    n = int(sd["mat_id"].shape[0])
+    keep["pos"] = _f32(sd["pos"]); keep["nrm"] = _f32(sd["nrm"]); keep["uv"] = _f32(sd["uv"]); keep["woop"] = _f32(sd["woop"])
+    keep["mat_id"] = np.ascontiguousarray(sd["mat_id"], dtype=np.int32)
+    mats = sd["materials"]
+    keep["materials"] = (Material * max(len(mats), 1))(*mats)
+    texs = [np.ascontiguousarray(t, dtype=np.uint8) for t in sd.get("textures", [])]
+    keep["texels"] = texs
+    tarr = (Texture * max(len(texs), 1))()
+    for i, t in enumerate(texs):
+        tarr[i].width, tarr[i].height, tarr[i].rgba = t.shape[1], t.shape[0], t.ctypes.data
+    keep["textures"] = tarr
+    keep["nodes"] = np.ascontiguousarray(sd["nodes"], dtype=FLATNODE_DTYPE)
+    keep["list"] = np.ascontiguousarray(sd["list"], dtype=np.int32)
+    d = SceneDesc()
+    d.num_tris = n
+    d.pos, d.nrm, d.uv, d.mat_id, d.woop = (_ptr(keep[k]) for k in ("pos", "nrm", "uv", "mat_id", "woop"))
+    d.num_materials, d.materials = len(mats), C.cast(keep["materials"], _P)
+    d.num_textures, d.textures = len(texs), C.cast(tarr, _P)
+    d.num_nodes, d.nodes = int(keep["nodes"].shape[0]), _ptr(keep["nodes"])
+    d.list_size, d.list = int(keep["list"].shape[0]), _ptr(keep["list"])
+    return d, keep
+
+
+class Scene:
+    def __init__(self, ctx, sd):
+        self.ctx, self.lib = ctx, ctx.lib
+        desc, keep = make_scene_desc(sd)
+        h = _P()
+        _check(self.lib.ptgpu_scene_create(ctx.handle, C.byref(desc), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.ptgpu_scene_destroy(self.handle)
+            self.handle = None
+
+    def stats(self):
+        b, d = (C.c_uint64 * 4)(), C.c_int32()
+        _check(self.lib.ptgpu_scene_stats(self.handle, C.byref(b), C.byref(d)))
+        return dict(inner_bytes=b[0], tri_bytes=b[1], shading_bytes=b[2], texture_bytes=b[3], depth=d.value)
+
+    def raycast(self, orig, direction, occlusion=False, use_alpha=True, want=("id", "t", "u", "v")):
+        """Host-pointer RayTracer::raycast batch. Returns dict of numpy arrays."""
+        o, d = _f32(orig).reshape(-1, 3), _f32(direction).reshape(-1, 3)
+        n = o.shape[0]
+        out = {k: np.empty(n, dtype=np.int32 if k == "id" else np.float32) for k in want}
+        _check(self.lib.ptgpu_raycast_batch(self.handle, int(use_alpha), o.ctypes.data, d.ctypes.data, n, int(occlusion),
+                                            _ptr(out.get("id")), _ptr(out.get("t")), _ptr(out.get("u")), _ptr(out.get("v"))))
+        return out
+
+    def raycast_dev(self, d_orig, d_dir, n, occlusion, d_id, d_t, d_u, d_v, use_alpha=True):
+        _check(self.lib.ptgpu_raycast_batch_dev(self.handle, int(use_alpha), d_orig, d_dir, n, int(occlusion), d_id, d_t, d_u, d_v))
+
+    def gen_shadow_dev(self, light, n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid):
+        _check(self.lib.ptgpu_gen_shadow_dev(self.handle, C.byref(light), n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid))

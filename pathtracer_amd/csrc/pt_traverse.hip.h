@@ -1,0 +1,216 @@
+// BVH traversal + Woop ray/triangle test for gfx950, one ray per lane (wave64).
+//
+// Restates RayTracer::raycast (reference src/RayTracer.cpp:174-290) with FlatNode::intersect
+// (src/BvhNode.cpp:9-57) and RTTriangle::intersect_woop (src/RTTriangle.hpp:50-59) so that the
+// hit record (triangle, t, u, v) is bit-identical to the CPU code:
+//
+//  * same arithmetic, same operation order, no FMA contraction, IEEE divide;
+//  * same node order: the child on the near side of the split axis first (sign[node.axis],
+//    RayTracer.cpp:263-271), leaves scanned startIdx..endIdx inclusive, a hit replaces the
+//    current one only if t > 0 && t < tmin (ties keep the first, :227), any-hit returns on the
+//    first accepted triangle (:235-238).
+//
+// Device layout (built by ptgpu_scene_create from the reference-layout 64-byte node array):
+//  * interior node = 64 B holding BOTH children's boxes and references, so one fetch decides
+//    two slab tests and a failing child never costs a dependent memory round trip.  The slab
+//    test of the far child is evaluated when its parent is visited; its entry distance is kept
+//    on the stack and re-compared with the ray's current tmin when popped.  That is exactly
+//    the test the reference performs at pop time, because only the final "tmin_box < t1"
+//    clause of FlatNode::intersect depends on t1 (BvhNode.cpp:56) and t1 only shrinks.
+//  * triangle record = 64 B in LEAF ORDER (no bvh.list indirection while scanning a leaf):
+//    three rows (M row | N) of the Woop matrix, then {triangle id, triangles remaining in this
+//    leaf, alpha-texture id or -1, material id}.
+//  * per-lane stack of {node ref, entry distance} pairs: the first NLDS entries live in LDS laid
+//    out [entry][lane] (conflict-free ds_read_b64/ds_write_b64), deeper entries spill to a
+//    private array.  Depth is bounded by the validated tree depth (<= 64 like the reference's
+//    int nodesToVisit[64]).
+#pragma once
+#include "pt_device.hip.h"
+
+namespace ptd {
+
+struct DevTexture {
+    const uint8_t* rgba;
+    int32_t width, height;
+};
+
+struct TravScene {
+    const float4* inner;  // [num_inner][4]
+    const float4* tris;   // [list_size][4]
+    float root_bmin[3], root_bmax[3];
+    int32_t root_ref;     // >= 0: interior node index; < 0: leaf starting at triangle record ~root_ref
+    int32_t list_size;    // 0 => empty scene, every ray misses
+    const float* uv;      // [num_tris][3][2], for the alpha cutout only
+    const DevTexture* textures;
+};
+
+struct HitRec {
+    int32_t id;  // caller's triangle index, -1 = miss
+    float t, u, v;
+};
+
+__device__ __forceinline__ float4 ldg4(const float4* p) { return *p; }
+
+// One child's slab test.  near*/far* are the box planes already selected by the ray's sign bits
+// (bounds[sign] / bounds[1-sign] in the reference).  Returns the t1-independent part of the result
+// in `ok` (both overlap checks and tmax > 0) and the entry distance in `tentry`.
+__device__ __forceinline__ void slab(float nx, float ny, float nz, float fx, float fy, float fz, F3 o, F3 inv,
+                                     bool& ok, float& tentry) {
+    float tmin = (nx - o.x) * inv.x;
+    float tmax = (fx - o.x) * inv.x;
+    float tymin = (ny - o.y) * inv.y;
+    float tymax = (fy - o.y) * inv.y;
+    bool miss = (tmin > tymax) || (tymin > tmax);
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (nz - o.z) * inv.z;
+    float tzmax = (fz - o.z) * inv.z;
+    miss = miss || (tmin > tzmax) || (tzmin > tmax);
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    ok = !miss && (tmax > 0.0f);
+    tentry = tmin;
+}
+
+template <int NLDS, bool OVF>
+struct LaneStack {
+    uint2* lds;  // this lane's slot of entry 0; entry e is lds[e * 64]
+    uint2 ovf[OVF ? (64 - NLDS) : 1];
+    int sp;
+    __device__ __forceinline__ void push(int ref, float tentry) {
+        uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tentry));
+        if (!OVF || sp < NLDS) lds[sp * 64] = e;
+        else ovf[sp - NLDS] = e;
+        ++sp;
+    }
+    __device__ __forceinline__ uint2 pop() {
+        --sp;
+        if (!OVF || sp < NLDS) return lds[sp * 64];
+        return ovf[sp - NLDS];
+    }
+};
+
+// ANYHIT: occlusion flag of raycast().  ALPHA: alpha-texture cutout enabled and present in the scene.
+// COUNT: also count the reference's node visits / triangle tests (far children are then always pushed so
+// that the counts equal the CPU traversal's exactly; results are unchanged).
+template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
+__device__ __forceinline__ HitRec traverse(const TravScene& S, F3 o, F3 d, uint2* lds_lane, uint32_t& n_nodes, uint32_t& n_tris) {
+    HitRec best;
+    best.id = -1; best.t = 3.402823466e+38f; best.u = 0.0f; best.v = 0.0f;
+    if (S.list_size <= 0) return best;
+
+    float tmin = 1.0f, umin = 0.0f, vmin = 0.0f;
+    int pmin = -1;
+    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    const uint32_t signbits = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
+
+    LaneStack<NLDS, OVF> st;
+    st.lds = lds_lane;
+    st.sp = 0;
+
+    int cur = S.root_ref;
+    bool alive;
+    {
+        bool ok; float te;
+        slab(sx ? S.root_bmax[0] : S.root_bmin[0], sy ? S.root_bmax[1] : S.root_bmin[1], sz ? S.root_bmax[2] : S.root_bmin[2],
+             sx ? S.root_bmin[0] : S.root_bmax[0], sy ? S.root_bmin[1] : S.root_bmax[1], sz ? S.root_bmin[2] : S.root_bmax[2],
+             o, inv, ok, te);
+        alive = ok && (te < tmin);
+        if (COUNT) n_nodes += 1;
+    }
+
+    while (alive) {
+        // ---- interior nodes: descend until this lane holds a leaf (or runs out of work) ----
+        while (alive && cur >= 0) {
+            const float4* np = S.inner + (size_t)cur * 4;
+            float4 a = ldg4(np), b = ldg4(np + 1), c = ldg4(np + 2), m = ldg4(np + 3);
+            // left box: min (a.x a.y a.z) max (a.w b.x b.y); right box: min (b.z b.w c.x) max (c.y c.z c.w)
+            bool okL, okR; float teL, teR;
+            slab(sx ? a.w : a.x, sy ? b.x : a.y, sz ? b.y : a.z, sx ? a.x : a.w, sy ? a.y : b.x, sz ? a.z : b.y, o, inv, okL, teL);
+            slab(sx ? c.y : b.z, sy ? c.z : b.w, sz ? c.w : c.x, sx ? b.z : c.y, sy ? b.w : c.z, sz ? c.x : c.w, o, inv, okR, teR);
+            int refL = __float_as_int(m.x), refR = __float_as_int(m.y);
+            bool rightFirst = ((signbits >> __float_as_int(m.z)) & 1u) != 0u;  // sign[node.axis]
+            int refN = rightFirst ? refR : refL, refF = rightFirst ? refL : refR;
+            bool okN = rightFirst ? okR : okL, okF = rightFirst ? okL : okR;
+            float teN = rightFirst ? teR : teL, teF = rightFirst ? teL : teR;
+            bool passN = okN && (teN < tmin);
+            bool passF = okF && (teF < tmin);
+            if (COUNT) {
+                n_nodes += 1;  // the near child is visited now; the far child when it is popped
+                st.push(refF, passF ? teF : __uint_as_float(0x7f800000u));
+                passF = false;
+            }
+            if (passN) {
+                if (passF) st.push(refF, teF);
+                cur = refN;
+            } else if (passF) {
+                cur = refF;
+            } else {
+                alive = false;
+                while (st.sp > 0) {
+                    uint2 e = st.pop();
+                    if (COUNT) n_nodes += 1;
+                    if (__uint_as_float(e.y) < tmin) { cur = (int)e.x; alive = true; break; }
+                }
+            }
+        }
+        if (!alive) break;
+
+        // ---- leaf: scan its triangle records ----
+        int pos = ~cur;
+        for (;;) {
+            const float4* tp = S.tris + (size_t)pos * 4;
+            float4 r0 = ldg4(tp), r1 = ldg4(tp + 1), r2 = ldg4(tp + 2), r3 = ldg4(tp + 3);
+            if (COUNT) n_tris += 1;
+            float ox = (r0.x * o.x + r0.y * o.y + r0.z * o.z) + r0.w;
+            float oy = (r1.x * o.x + r1.y * o.y + r1.z * o.z) + r1.w;
+            float oz = (r2.x * o.x + r2.y * o.y + r2.z * o.z) + r2.w;
+            float dx = r0.x * d.x + r0.y * d.y + r0.z * d.z;
+            float dy = r1.x * d.x + r1.y * d.y + r1.z * d.z;
+            float dz = r2.x * d.x + r2.y * d.y + r2.z * d.z;
+            float t = -oz / dz;
+            float u = ox + dx * t;
+            float v = oy + dy * t;
+            if (u > 0.0f && v > 0.0f && u + v < 1.0f) {
+                bool keep = true;
+                if (ALPHA) {
+                    int atex = __float_as_int(r3.z);
+                    if (atex >= 0) {  // RayTracer.cpp:204-225: green channel of the alpha map < 0.5 => cut out
+                        const float* tc = S.uv + (size_t)__float_as_int(r3.x) * 6;
+                        F2 uv = (1 - u - v) * ld2(tc) + u * ld2(tc + 2) + v * ld2(tc + 4);
+                        DevTexture tx = S.textures[atex];
+                        int x = (int)((uv.x - floorf(uv.x)) * tx.width);
+                        int y = (int)((uv.y - floorf(uv.y)) * tx.height);
+                        x = x < 0 ? 0 : (x > tx.width - 1 ? tx.width - 1 : x);
+                        y = y < 0 ? 0 : (y > tx.height - 1 ? tx.height - 1 : y);
+                        float alpha = (float)tx.rgba[((size_t)y * tx.width + x) * 4 + 1] / 255.0f;
+                        keep = !(alpha < 0.5f);
+                    }
+                }
+                if (keep && t > 0.0f && t < tmin) {
+                    pmin = pos; tmin = t; umin = u; vmin = v;
+                    if (ANYHIT) { alive = false; break; }
+                }
+            }
+            if (__float_as_int(r3.y) == 0) break;
+            ++pos;
+        }
+        if (ANYHIT && !alive) break;
+
+        // ---- next node from the stack ----
+        alive = false;
+        while (st.sp > 0) {
+            uint2 e = st.pop();
+            if (COUNT) n_nodes += 1;
+            if (__uint_as_float(e.y) < tmin) { cur = (int)e.x; alive = true; break; }
+        }
+    }
+    if (pmin >= 0) {
+        best.id = __float_as_int(S.tris[(size_t)pmin * 4 + 3].x);
+        best.t = tmin; best.u = umin; best.v = vmin;
+    }
+    return best;
+}
+
+}  // namespace ptd

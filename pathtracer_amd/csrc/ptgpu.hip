@@ -1,0 +1,514 @@
+// libptgpu.so -- C ABI (include/ptgpu.h) over the gfx950 kernels.  Pure HIP: no torch types, no CPU fallback.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ptgpu.h"
+#include "pt_traverse.hip.h"
+
+namespace ptd {
+__device__ const uint32_t g_sobol_matrices[1024 * 52] = {
+#include "_gen/sobol_matrices.inc"
+};
+}
+
+static_assert(sizeof(ptgpu_flatnode) == 64, "FlatNode must be 64 bytes like the reference's");
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PTGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct ptgpu_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool count = false;
+    unsigned long long* d_counters = nullptr;  // rays, node visits, triangle tests
+};
+
+struct ptgpu_scene {
+    ptgpu_context* ctx = nullptr;
+    ptd::TravScene trav{};
+    int32_t num_tris = 0, num_inner = 0, depth = 0;
+    bool has_alpha = false;
+    // device allocations
+    float4* d_inner = nullptr;
+    float4* d_tris = nullptr;
+    float *d_pos = nullptr, *d_nrm = nullptr, *d_uv = nullptr;
+    int32_t* d_mat_id = nullptr;
+    ptgpu_material* d_materials = nullptr;
+    ptd::DevTexture* d_textures = nullptr;
+    std::vector<uint8_t*> d_texels;
+    int32_t num_materials = 0, num_textures = 0;
+    uint64_t bytes[4] = {0, 0, 0, 0};
+};
+
+extern "C" const char* ptgpu_last_error(void) { return g_err; }
+
+extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
+    if (!out_ctx) return fail(PTGPU_E_INVALID, "out_ctx is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PTGPU_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(PTGPU_E_INVALID, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PTGPU_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    ptgpu_context* c = new ptgpu_context();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)));
+    *out_ctx = c;
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_shutdown(ptgpu_context* c) {
+    if (!c) return PTGPU_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->d_counters) hipFree(c->d_counters);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_set_stream(ptgpu_context* c, void* s) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_sync(ptgpu_context* c) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_malloc(ptgpu_context* c, uint64_t bytes, void** out) {
+    if (!c || !out) return fail(PTGPU_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 4));
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_free(ptgpu_context* c, void* p) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (p) HIP_TRY(hipFree(p));
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_memcpy_h2d(ptgpu_context* c, void* dev, const void* host, uint64_t bytes) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    if (!bytes) return PTGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_memcpy_d2h(ptgpu_context* c, void* host, const void* dev, uint64_t bytes) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    if (!bytes) return PTGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_memset(ptgpu_context* c, void* dev, int value, uint64_t bytes) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    if (!bytes) return PTGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(dev, value, bytes, c->stream));
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_enable_counters(ptgpu_context* c, int on) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    c->count = on != 0;
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_get_counters(ptgpu_context* c, ptgpu_counters* out) {
+    if (!c || !out) return fail(PTGPU_E_INVALID, "NULL argument");
+    unsigned long long h[3];
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2];
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_reset_counters(ptgpu_context* c) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));
+    return PTGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene creation: validate the reference-layout tree, build the traversal layout, upload
+// ------------------------------------------------------------------------------------------------
+template <class T> static int upload(ptgpu_context* c, T** dptr, const T* h, size_t n, uint64_t* acc) {
+    size_t bytes = n * sizeof(T);
+    HIP_TRY(hipMalloc((void**)dptr, bytes ? bytes : 4));
+    if (bytes) HIP_TRY(hipMemcpy(*dptr, h, bytes, hipMemcpyHostToDevice));
+    if (acc) *acc += bytes;
+    return PTGPU_OK;
+}
+
+static int child_ref(const ptgpu_flatnode* nodes, const std::vector<int32_t>& inner_index, int child) {
+    return nodes[child].leaf ? ~nodes[child].startIdx : inner_index[child];
+}
+
+static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene* s) {
+    const int32_t nn = d->num_nodes, nl = d->list_size, nt = d->num_tris;
+    if (nt < 0 || nn < 0 || nl < 0) return fail(PTGPU_E_INVALID, "negative count in scene description");
+    if (nt > 0 && (!d->pos || !d->nrm || !d->uv || !d->mat_id || !d->woop))
+        return fail(PTGPU_E_INVALID, "triangle arrays missing");
+    if (d->num_materials < 0 || (d->num_materials > 0 && !d->materials)) return fail(PTGPU_E_INVALID, "materials missing");
+    if (d->num_textures < 0 || (d->num_textures > 0 && !d->textures)) return fail(PTGPU_E_INVALID, "textures missing");
+    for (int i = 0; i < nt; ++i)
+        if (d->mat_id[i] < 0 || d->mat_id[i] >= d->num_materials)
+            return fail(PTGPU_E_INVALID, "triangle %d: material index %d out of range", i, d->mat_id[i]);
+    for (int i = 0; i < d->num_materials; ++i) {
+        const int32_t t[4] = {d->materials[i].tex_diffuse, d->materials[i].tex_alpha, d->materials[i].tex_normal, d->materials[i].tex_specular};
+        for (int k = 0; k < 4; ++k)
+            if (t[k] < -1 || t[k] >= d->num_textures) return fail(PTGPU_E_INVALID, "material %d: texture index %d out of range", i, t[k]);
+    }
+    for (int i = 0; i < d->num_textures; ++i)
+        if (d->textures[i].width < 2 || d->textures[i].height < 2 || !d->textures[i].rgba)
+            return fail(PTGPU_E_INVALID, "texture %d: needs width,height >= 2 and pixel data", i);
+
+    s->num_tris = nt;
+    s->num_materials = d->num_materials;
+    s->num_textures = d->num_textures;
+    std::vector<float4> inner, tris;
+    int depth = 0;
+    if (nn > 0) {
+        if (!d->nodes || !d->list || nl <= 0 || nt <= 0) return fail(PTGPU_E_INVALID, "BVH given without nodes/list/triangles");
+        for (int i = 0; i < nl; ++i)
+            if (d->list[i] < 0 || d->list[i] >= nt) return fail(PTGPU_E_INVALID, "list[%d] = %d out of range", i, d->list[i]);
+        // Walk the tree exactly as the flattened layout promises (left child = index + 1, Bvh.cpp:85) and check that it is a
+        // tree over [0, num_nodes) whose leaves tile the list in order; anything else could make a kernel loop or fault.
+        std::vector<int32_t> inner_index(nn, -1);
+        std::vector<uint8_t> seen(nn, 0);
+        struct Item { int node, depth; };
+        std::vector<Item> stack;
+        stack.push_back({0, 1});
+        int next_list = 0, n_inner = 0;
+        while (!stack.empty()) {
+            Item it = stack.back();
+            stack.pop_back();
+            if (it.node < 0 || it.node >= nn) return fail(PTGPU_E_INVALID, "child index %d out of range", it.node);
+            if (seen[it.node]) return fail(PTGPU_E_INVALID, "node %d reachable twice (not a tree)", it.node);
+            seen[it.node] = 1;
+            const ptgpu_flatnode& n = d->nodes[it.node];
+            if (it.depth > depth) depth = it.depth;
+            if (n.leaf) {
+                if (n.startIdx != next_list || n.endIdx < n.startIdx || n.endIdx >= nl)
+                    return fail(PTGPU_E_INVALID, "leaf %d: range [%d,%d] does not continue the list at %d", it.node, n.startIdx, n.endIdx, next_list);
+                next_list = n.endIdx + 1;
+            } else {
+                if (n.axis < 0 || n.axis > 2) return fail(PTGPU_E_INVALID, "node %d: axis %d", it.node, n.axis);
+                if (n.rightChild <= it.node + 1 || n.rightChild >= nn) return fail(PTGPU_E_INVALID, "node %d: rightChild %d", it.node, n.rightChild);
+                inner_index[it.node] = n_inner++;
+                stack.push_back({n.rightChild, it.depth + 1});
+                stack.push_back({it.node + 1, it.depth + 1});  // popped first: pre-order
+            }
+        }
+        if (next_list != nl) return fail(PTGPU_E_INVALID, "leaves cover %d of %d list entries", next_list, nl);
+        if (depth > 64) return fail(PTGPU_E_UNSUPPORTED, "tree depth %d exceeds 64 (the reference's traversal stack, RayTracer.cpp:190)", depth);
+
+        inner.resize((size_t)n_inner * 4);
+        for (int i = 0; i < nn; ++i) {
+            if (inner_index[i] < 0) continue;
+            const ptgpu_flatnode& n = d->nodes[i];
+            const ptgpu_flatnode& L = d->nodes[i + 1];
+            const ptgpu_flatnode& R = d->nodes[n.rightChild];
+            float4* o = &inner[(size_t)inner_index[i] * 4];
+            o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], L.bmax[0]);
+            o[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
+            o[2] = make_float4(R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
+            int refL = child_ref(d->nodes, inner_index, i + 1), refR = child_ref(d->nodes, inner_index, n.rightChild);
+            float fl, fr, fa;
+            int32_t ax = n.axis;
+            memcpy(&fl, &refL, 4); memcpy(&fr, &refR, 4); memcpy(&fa, &ax, 4);
+            o[3] = make_float4(fl, fr, fa, 0.0f);
+        }
+        tris.resize((size_t)nl * 4);
+        for (int i = 0; i < nn; ++i) {
+            const ptgpu_flatnode& n = d->nodes[i];
+            if (!n.leaf) continue;
+            for (int p = n.startIdx; p <= n.endIdx; ++p) {
+                int32_t id = d->list[p], remaining = n.endIdx - p, mat = d->mat_id[id];
+                int32_t atex = d->materials[mat].tex_alpha;
+                if (atex >= 0) s->has_alpha = true;
+                const float* w = d->woop + (size_t)id * 12;
+                float4* o = &tris[(size_t)p * 4];
+                o[0] = make_float4(w[0], w[1], w[2], w[3]);
+                o[1] = make_float4(w[4], w[5], w[6], w[7]);
+                o[2] = make_float4(w[8], w[9], w[10], w[11]);
+                float f0, f1, f2, f3;
+                memcpy(&f0, &id, 4); memcpy(&f1, &remaining, 4); memcpy(&f2, &atex, 4); memcpy(&f3, &mat, 4);
+                o[3] = make_float4(f0, f1, f2, f3);
+            }
+        }
+        const ptgpu_flatnode& root = d->nodes[0];
+        for (int k = 0; k < 3; ++k) { s->trav.root_bmin[k] = root.bmin[k]; s->trav.root_bmax[k] = root.bmax[k]; }
+        s->trav.root_ref = root.leaf ? ~root.startIdx : 0;
+        s->trav.list_size = nl;
+        s->num_inner = n_inner;
+    } else {
+        s->trav.list_size = 0;  // empty scene: every ray misses
+        s->trav.root_ref = -1;
+    }
+    s->depth = depth;
+
+    int rc;
+    if ((rc = upload(c, &s->d_inner, inner.data(), inner.size(), &s->bytes[0]))) return rc;
+    if ((rc = upload(c, &s->d_tris, tris.data(), tris.size(), &s->bytes[1]))) return rc;
+    if ((rc = upload(c, &s->d_pos, d->pos, (size_t)nt * 9, &s->bytes[2]))) return rc;
+    if ((rc = upload(c, &s->d_nrm, d->nrm, (size_t)nt * 9, &s->bytes[2]))) return rc;
+    if ((rc = upload(c, &s->d_uv, d->uv, (size_t)nt * 6, &s->bytes[2]))) return rc;
+    if ((rc = upload(c, &s->d_mat_id, d->mat_id, (size_t)nt, &s->bytes[2]))) return rc;
+    if ((rc = upload(c, &s->d_materials, d->materials, (size_t)d->num_materials, &s->bytes[2]))) return rc;
+    std::vector<ptd::DevTexture> tex(d->num_textures);
+    for (int i = 0; i < d->num_textures; ++i) {
+        uint8_t* p = nullptr;
+        if ((rc = upload(c, &p, d->textures[i].rgba, (size_t)d->textures[i].width * d->textures[i].height * 4, &s->bytes[3]))) return rc;
+        s->d_texels.push_back(p);
+        tex[i].rgba = p; tex[i].width = d->textures[i].width; tex[i].height = d->textures[i].height;
+    }
+    if ((rc = upload(c, &s->d_textures, tex.data(), tex.size(), &s->bytes[3]))) return rc;
+    s->trav.inner = s->d_inner;
+    s->trav.tris = s->d_tris;
+    s->trav.uv = s->d_uv;
+    s->trav.textures = s->d_textures;
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_scene_destroy(ptgpu_scene* s) {
+    if (!s) return PTGPU_OK;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    void* ptrs[] = {s->d_inner, s->d_tris, s->d_pos, s->d_nrm, s->d_uv, s->d_mat_id, s->d_materials, s->d_textures};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (uint8_t* p : s->d_texels) if (p) hipFree(p);
+    delete s;
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_scene_create(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene** out) {
+    if (!c || !d || !out) return fail(PTGPU_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    ptgpu_scene* s = new ptgpu_scene();
+    s->ctx = c;
+    int rc = build_scene(c, d, s);
+    if (rc != PTGPU_OK) {
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        ptgpu_scene_destroy(s);
+        memcpy(g_err, keep, sizeof keep);
+        return rc;
+    }
+    *out = s;
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_scene_stats(const ptgpu_scene* s, uint64_t out_bytes[4], int32_t* out_depth) {
+    if (!s) return fail(PTGPU_E_INVALID, "scene is NULL");
+    if (out_bytes) for (int i = 0; i < 4; ++i) out_bytes[i] = s->bytes[i];
+    if (out_depth) *out_depth = s->depth;
+    return PTGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int RC_BLOCK = 256;  // 4 waves
+constexpr int RC_NLDS = 16;    // stack entries per lane kept in LDS (8 KiB per wave)
+
+template <bool ANYHIT, bool ALPHA, bool COUNT, bool OVF>
+__global__ __launch_bounds__(RC_BLOCK) void k_raycast(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
+                                                      long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
+                                                      float* __restrict__ out_u, float* __restrict__ out_v, unsigned long long* counters) {
+    __shared__ uint2 lds_stack[RC_BLOCK / 64][RC_NLDS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
+    uint32_t n_nodes = 0, n_tris = 0;
+    if (i < n) {
+        ptd::F3 o = ptd::ld3(orig + i * 3), d = ptd::ld3(dir + i * 3);
+        ptd::HitRec h = ptd::traverse<ANYHIT, ALPHA, COUNT, RC_NLDS, OVF>(S, o, d, &lds_stack[wave][0][lane], n_nodes, n_tris);
+        if (out_id) out_id[i] = h.id;
+        if (out_t) out_t[i] = h.t;
+        if (out_u) out_u[i] = h.u;
+        if (out_v) out_v[i] = h.v;
+    }
+    if (COUNT) {
+        atomicAdd(&counters[1], (unsigned long long)n_nodes);
+        atomicAdd(&counters[2], (unsigned long long)n_tris);
+    }
+}
+
+__global__ void k_add_rays(unsigned long long* counters, unsigned long long n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], n);
+}
+
+template <bool ANYHIT, bool ALPHA, bool COUNT>
+static void launch_raycast2(ptgpu_scene* s, bool ovf, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
+    dim3 grid((unsigned)((n + RC_BLOCK - 1) / RC_BLOCK)), block(RC_BLOCK);
+    hipStream_t st = s->ctx->stream;
+    if (ovf) hipLaunchKernelGGL((k_raycast<ANYHIT, ALPHA, COUNT, true>), grid, block, 0, st, s->trav, o, d, n, id, t, u, v, s->ctx->d_counters);
+    else hipLaunchKernelGGL((k_raycast<ANYHIT, ALPHA, COUNT, false>), grid, block, 0, st, s->trav, o, d, n, id, t, u, v, s->ctx->d_counters);
+}
+template <bool ANYHIT, bool ALPHA>
+static void launch_raycast1(ptgpu_scene* s, bool count, bool ovf, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
+    if (count) launch_raycast2<ANYHIT, ALPHA, true>(s, ovf, o, d, n, id, t, u, v);
+    else launch_raycast2<ANYHIT, ALPHA, false>(s, ovf, o, d, n, id, t, u, v);
+}
+
+extern "C" int ptgpu_raycast_batch_dev(ptgpu_scene* s, int use_alpha, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
+                                       int32_t* d_id, float* d_t, float* d_u, float* d_v) {
+    if (!s) return fail(PTGPU_E_INVALID, "scene is NULL");
+    if (n < 0) return fail(PTGPU_E_INVALID, "n < 0");
+    if (n == 0) return PTGPU_OK;
+    if (!d_orig || !d_dir) return fail(PTGPU_E_INVALID, "ray arrays are NULL");
+    if ((n + RC_BLOCK - 1) / RC_BLOCK > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large for one launch");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    const bool alpha = use_alpha && s->has_alpha, count = s->ctx->count;
+    // stack occupancy <= depth - 1 (one far sibling per ancestor level); counting mode pushes every far child too
+    const bool ovf = (s->depth - 1) > RC_NLDS;
+    if (occlusion) {
+        if (alpha) launch_raycast1<true, true>(s, count, ovf, d_orig, d_dir, n, d_id, d_t, d_u, d_v);
+        else launch_raycast1<true, false>(s, count, ovf, d_orig, d_dir, n, d_id, d_t, d_u, d_v);
+    } else {
+        if (alpha) launch_raycast1<false, true>(s, count, ovf, d_orig, d_dir, n, d_id, d_t, d_u, d_v);
+        else launch_raycast1<false, false>(s, count, ovf, d_orig, d_dir, n, d_id, d_t, d_u, d_v);
+    }
+    hipLaunchKernelGGL(k_add_rays, dim3(1), dim3(64), 0, s->ctx->stream, s->ctx->d_counters, (unsigned long long)n);
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_raycast_batch(ptgpu_scene* s, int use_alpha, const float* orig, const float* dir, int64_t n, int occlusion,
+                                   int32_t* out_id, float* out_t, float* out_u, float* out_v) {
+    if (!s) return fail(PTGPU_E_INVALID, "scene is NULL");
+    if (n < 0) return fail(PTGPU_E_INVALID, "n < 0");
+    if (n == 0) return PTGPU_OK;
+    if (!orig || !dir) return fail(PTGPU_E_INVALID, "ray arrays are NULL");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    hipStream_t st = s->ctx->stream;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_u = nullptr, *d_v = nullptr;
+    int32_t* d_id = nullptr;
+    int rc = PTGPU_OK;
+    auto cleanup = [&]() { for (void* p : {(void*)d_o, (void*)d_d, (void*)d_t, (void*)d_u, (void*)d_v, (void*)d_id}) if (p) hipFree(p); };
+#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(PTGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    TRY2(hipMalloc(&d_o, n * 12)); TRY2(hipMalloc(&d_d, n * 12));
+    if (out_id) TRY2(hipMalloc(&d_id, n * 4));
+    if (out_t) TRY2(hipMalloc(&d_t, n * 4));
+    if (out_u) TRY2(hipMalloc(&d_u, n * 4));
+    if (out_v) TRY2(hipMalloc(&d_v, n * 4));
+    TRY2(hipMemcpyAsync(d_o, orig, n * 12, hipMemcpyHostToDevice, st));
+    TRY2(hipMemcpyAsync(d_d, dir, n * 12, hipMemcpyHostToDevice, st));
+    rc = ptgpu_raycast_batch_dev(s, use_alpha, d_o, d_d, n, occlusion, d_id, d_t, d_u, d_v);
+    if (rc != PTGPU_OK) { cleanup(); return rc; }
+    if (out_id) TRY2(hipMemcpyAsync(out_id, d_id, n * 4, hipMemcpyDeviceToHost, st));
+    if (out_t) TRY2(hipMemcpyAsync(out_t, d_t, n * 4, hipMemcpyDeviceToHost, st));
+    if (out_u) TRY2(hipMemcpyAsync(out_u, d_u, n * 4, hipMemcpyDeviceToHost, st));
+    if (out_v) TRY2(hipMemcpyAsync(out_v, d_v, n * 4, hipMemcpyDeviceToHost, st));
+    TRY2(hipStreamSynchronize(st));
+#undef TRY2
+    cleanup();
+    return PTGPU_OK;
+}
+
+// ---- ray generators for BASELINE config 2 ----
+__device__ __forceinline__ void camera_ray_nodof(const ptgpu_camera& cam, float x, float y, ptd::F3& Ro, ptd::F3& Rd) {
+    ptd::F4 a = ptd::mul44(cam.invP, x, y, 0.0f, 1.0f);
+    float ia = 1.0f / a.w;
+    Ro = ptd::f3(a.x * ia, a.y * ia, a.z * ia);
+    ptd::F4 b = ptd::mul44(cam.invP, x, y, 1.0f, 1.0f);
+    float ib = 1.0f / b.w;
+    Rd = ptd::f3(b.x * ib, b.y * ib, b.z * ib) - Ro;
+}
+
+__global__ void k_gen_primary(ptgpu_camera cam, int width, int height, float* __restrict__ orig, float* __restrict__ dir) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)width * height) return;
+    int px = (int)(i % width), py = (int)(i / width);
+    float div_x = 1.0f / (float)width, div_y = 1.0f / (float)height;
+    float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    float x = fx * div_x * 2.0f - 1.0f;
+    float y = fy * div_y * -2.0f + 1.0f;
+    ptd::F3 Ro, Rd;
+    camera_ray_nodof(cam, x, y, Ro, Rd);
+    orig[i * 3] = Ro.x; orig[i * 3 + 1] = Ro.y; orig[i * 3 + 2] = Ro.z;
+    dir[i * 3] = Rd.x; dir[i * 3 + 1] = Rd.y; dir[i * 3 + 2] = Rd.z;
+}
+
+__global__ void k_gen_shadow(const float* __restrict__ nrm, int num_tris, ptgpu_light L, long long n, const float* __restrict__ orig,
+                             const float* __restrict__ dir, const int32_t* __restrict__ id, const float* __restrict__ t,
+                             const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ so, float* __restrict__ sd,
+                             int32_t* __restrict__ valid) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int tri = id[i];
+    ptd::F3 o = ptd::f3(0, 0, 0), d = ptd::f3(0, 0, 0);
+    if (tri >= num_tris) tri = -1;  // never index past the scene with a caller-supplied id
+    if (tri >= 0) {
+        ptd::F3 O = ptd::ld3(orig + i * 3) + t[i] * ptd::ld3(dir + i * 3);
+        const float* nn = nrm + (size_t)tri * 9;
+        float uu = u[i], vv = v[i];
+        ptd::F3 N = ptd::normalize((1 - uu - vv) * ptd::ld3(nn) + uu * ptd::ld3(nn + 3) + vv * ptd::ld3(nn + 6));
+        float x = (2.0f * ptd::sobol_sample((unsigned long long)i, 4) - 1.0f) * L.size[0];
+        float y = (2.0f * ptd::sobol_sample((unsigned long long)i, 5) - 1.0f) * L.size[1];
+        ptd::F3 Pl = ptd::f3(L.xform[12], L.xform[13], L.xform[14]) + ptd::f3(L.xform[0], L.xform[1], L.xform[2]) * x +
+                     ptd::f3(L.xform[4], L.xform[5], L.xform[6]) * y;
+        o = O + 0.0001f * N;
+        d = Pl - O;
+    }
+    valid[i] = tri >= 0 ? 1 : 0;
+    so[i * 3] = o.x; so[i * 3 + 1] = o.y; so[i * 3 + 2] = o.z;
+    sd[i * 3] = d.x; sd[i * 3 + 1] = d.y; sd[i * 3 + 2] = d.z;
+}
+
+extern "C" int ptgpu_gen_primary_dev(ptgpu_context* c, const ptgpu_camera* cam, int32_t width, int32_t height, float* d_orig, float* d_dir) {
+    if (!c || !cam || !d_orig || !d_dir) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (width <= 0 || height <= 0) return fail(PTGPU_E_INVALID, "image size %dx%d", width, height);
+    HIP_TRY(hipSetDevice(c->device));
+    long long n = (long long)width * height;
+    hipLaunchKernelGGL(k_gen_primary, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, *cam, width, height, d_orig, d_dir);
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_gen_shadow_dev(ptgpu_scene* s, const ptgpu_light* light, int64_t n, const float* d_orig, const float* d_dir,
+                                    const int32_t* d_id, const float* d_t, const float* d_u, const float* d_v, float* d_sh_orig,
+                                    float* d_sh_dir, int32_t* d_sh_valid) {
+    if (!s || !light) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (n < 0) return fail(PTGPU_E_INVALID, "n < 0");
+    if (n == 0) return PTGPU_OK;
+    if (!d_orig || !d_dir || !d_id || !d_t || !d_u || !d_v || !d_sh_orig || !d_sh_dir || !d_sh_valid)
+        return fail(PTGPU_E_INVALID, "NULL device array");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    hipLaunchKernelGGL(k_gen_shadow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->ctx->stream, s->d_nrm, s->num_tris, *light, (long long)n,
+                       d_orig, d_dir, d_id, d_t, d_u, d_v, d_sh_orig, d_sh_dir, d_sh_valid);
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
+}
