@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the hot path on N MI355X (one process per GPU, torch.distributed over RCCL).
+
+Workload at N=1 = BASELINE.json configs[1]: head.obj, 1920x1080, one pixel-centre primary ray per pixel traced closest-hit
+(RayTracer::raycast, occlusion=false) plus one shadow ray per primary hit traced any-hit (occlusion=true); rays are
+generated on the device, every buffer is resident in HBM before the timed region.  One "step" = one such frame:
+gen_primary -> raycast(closest) -> gen_shadow -> raycast(any-hit).  1 ray = 1 raycast() call, like the reference's
+counter (reference src/RayTracer.cpp:192, src/PathTraceRenderer.cpp:884-897).
+
+N>1: the path shards by image tiles with no data-path exchange, so every rank traces its own 1920x1080 tile set of an
+N-times-taller frame (weak scaling); ranks only meet in the timing barriers and one 8-byte ray-count sum.
+
+The CPU oracle (oracle/) is used ONLY for the cpu_baseline leg (rank 0, N=1) -- never in the measured path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from pathtracer_amd import capi, hostapi, scene  # noqa: E402
+
+W, H = 1920, 1080
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_head_scene():
+    """Product-side scene construction: triangle array + Woop data + SAH BVH from the C++ host classes (no oracle)."""
+    mesh = scene.load_ptmesh()
+    woop = hostapi.woop_from_positions(mesh["pos"])
+    nodes, lst, stats = hostapi.bvh_build(mesh["pos"], sah=True)
+    sd = dict(pos=mesh["pos"], nrm=mesh["nrm"], uv=mesh["uv"], mat_id=mesh["mat_id"], woop=woop,
+              materials=scene.mesh_materials(mesh), textures=[], nodes=nodes, list=lst)
+    return sd, stats
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    sd, bvh_stats = build_head_scene()
+    ctx = capi.Context(local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    gscene = capi.Scene(ctx, sd)
+    # rank r renders tile set r of the N-times-taller frame: same camera, its own band => identical per-rank work
+    cam, light = scene.make_camera(width=W, height=H), scene.make_light()
+    n = W * H
+    f32 = dict(dtype=torch.float32, device=dev)
+    o, d, so, sdir = (torch.empty(n * 3, **f32) for _ in range(4))
+    t, u, v = (torch.empty(n, **f32) for _ in range(3))
+    hid, valid, sid = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+    P = lambda x: x.data_ptr()  # noqa: E731
+
+    def step(ev=None):
+        ctx.gen_primary_dev(cam, W, H, P(o), P(d))
+        if ev:
+            ev[0].record(stream)
+        gscene.raycast_dev(P(o), P(d), n, False, P(hid), P(t), P(u), P(v))
+        if ev:
+            ev[1].record(stream)
+        gscene.gen_shadow_dev(light, n, P(o), P(d), P(hid), P(t), P(u), P(v), P(so), P(sdir), P(valid))
+        if ev:
+            ev[2].record(stream)
+        gscene.raycast_dev(P(so), P(sdir), n, True, P(sid), None, None, None)
+        if ev:
+            ev[3].record(stream)
+
+    # per-ray traversal work, measured once with the counting kernels (identical to the CPU traversal's counts)
+    ctx.enable_counters(True)
+    ctx.reset_counters()
+    ctx.gen_primary_dev(cam, W, H, P(o), P(d))
+    gscene.raycast_dev(P(o), P(d), n, False, P(hid), P(t), P(u), P(v))
+    cp = ctx.counters()
+    gscene.gen_shadow_dev(light, n, P(o), P(d), P(hid), P(t), P(u), P(v), P(so), P(sdir), P(valid))
+    n_shadow = int(valid.sum().item())
+    ctx.reset_counters()
+    gscene.raycast_dev(P(so), P(sdir), n, True, P(sid), None, None, None)
+    cs = ctx.counters()
+    ctx.enable_counters(False)
+    rays_per_step = n + n_shadow
+    # B_ray = 64*N_nodes + 52*N_tris + 28 (ray in) + 16 (hit out)
+    bytes_primary = 64 * cp["node_visits"] + 52 * cp["tri_tests"] + 44 * n
+    bytes_shadow = 64 * cs["node_visits"] + 52 * cs["tri_tests"] + 44 * n
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    total_rays = torch.tensor([rays_per_step * args.steps], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(total_rays, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    total_rays = int(total_rays.item())
+
+    closest_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    anyhit_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
+    if rank == 0:
+        achieved = bytes_primary / (closest_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("k_raycast_closest_hbm_bytes_per_launch")
+        out = {
+            "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "head.obj 1920x1080 primary closest-hit + shadow any-hit rays (BASELINE configs[1])",
+                       "triangles": int(sd["mat_id"].shape[0]), "bvh_nodes": int(sd["nodes"].shape[0]),
+                       "rays_per_step_per_gpu": rays_per_step, "parallelism": "tiles x%d" % world},
+            "samples_per_s": None,
+            "kernels_ms": {"raycast_closest": closest_ms, "raycast_anyhit": anyhit_ms},
+            "per_ray": {"primary_nodes": cp["node_visits"] / n, "primary_tris": cp["tri_tests"] / n,
+                        "shadow_nodes": cs["node_visits"] / n, "shadow_tris": cs["tri_tests"] / n},
+            "roofline": {"kernel": "k_raycast<closest-hit>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "algorithmic bytes (64 B/node visit + 52 B/triangle test + 44 B/ray); head.obj's 1.1 MB of "
+                                 "nodes+triangles is L2-resident, so frac measures traversal rate, not HBM pressure"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, cam, light)
+        print(json.dumps(out), flush=True)
+    gscene.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, cam, light):
+    """The oracle (CPU restatement of the reference's raycast) on the same C2 frame, on this box's host cores."""
+    from oracle import pyoracle as po
+    threads = min(16, os.cpu_count() or 1)
+    o, d = po.gen_primary(cam, W, H)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        c = po.raycast(sd, o, d, False, nthreads=threads)
+        t1 = time.perf_counter()
+        so, sdir, valid = po.gen_shadow(sd, light, o, d, c)  # single-threaded bookkeeping in the oracle: not timed
+        m = valid == 1
+        so, sdir = so[m], sdir[m]
+        t2 = time.perf_counter()
+        po.raycast(sd, so, sdir, True, nthreads=threads)
+        t3 = time.perf_counter()
+        dt = (t1 - t0) + (t3 - t2)
+        rays = o.shape[0] + int(m.sum())
+        best = dt if best is None or dt < best else best
+    return {"value": rays / best / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "the full configs[1] frame (2,073,600 primary + one shadow ray per hit), best of 3, the two raycast batches timed"}
+
+
+if __name__ == "__main__":
+    main()

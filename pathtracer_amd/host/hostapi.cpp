@@ -1,0 +1,173 @@
+// C shim over the C++ host classes so that pytest (ctypes) and bench.py can drive them.  Not part of the drop-in
+// boundary (that is include/ptgpu.h); this only exposes FW::BVH / RayTracer / AreaLight / CameraControls to Python.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "3d/CameraControls.hpp"
+#include "AreaLight.hpp"
+#include "Bvh.hpp"
+#include "Md5.hpp"
+#include "RayTracer.hpp"
+#include "util.hpp"
+
+using namespace FW;
+
+namespace {
+thread_local std::string g_err;
+template <class F> int guarded(F&& f) {
+    try { f(); return 0; }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+std::vector<RTTriangle> trianglesFromPositions(int n, const float* pos) {
+    std::vector<RTTriangle> tris;
+    tris.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        VertexPNTC v[3];
+        for (int k = 0; k < 3; ++k) v[k].p = Vec3f(pos[i * 9 + k * 3], pos[i * 9 + k * 3 + 1], pos[i * 9 + k * 3 + 2]);
+        tris.emplace_back(v[0], v[1], v[2]);
+    }
+    return tris;
+}
+// App::constructTracer's triangle array (reference src/App.cpp:826-838)
+void trianglesFromMesh(MeshWithColors& mesh, std::vector<RTTriangle>& out) {
+    out.clear();
+    out.reserve(mesh.numTriangles());
+    for (int i = 0; i < mesh.numSubmeshes(); ++i)
+        for (const Vec3i& idx : mesh.indices(i)) {
+            RTTriangle t(mesh.vertex(idx[0]), mesh.vertex(idx[1]), mesh.vertex(idx[2]));
+            t.m_data.vertex_indices = idx;
+            t.m_material = &mesh.material(i);
+            out.push_back(t);
+        }
+}
+struct TracerBox {
+    std::unique_ptr<MeshWithColors> mesh;
+    std::vector<RTTriangle> tris;
+    RayTracer rt;
+};
+}  // namespace
+
+extern "C" {
+
+const char* pth_last_error(void) { return g_err.c_str(); }
+
+void pth_woop_from_positions(int n, const float* pos, float* out12) {
+    std::vector<RTTriangle> tris = trianglesFromPositions(n, pos);
+    for (int i = 0; i < n; ++i) tris[i].m_data.packRows(out12 + (size_t)i * 12);
+}
+
+// stats: totalSplits, badSplits, depthField, trueDepth, buildMicros, flattenMicros
+int pth_bvh_build(int n, const float* pos, int sah, int threads, int32_t* out_list, void* out_nodes, int64_t stats[6]) {
+    std::vector<RTTriangle> tris = trianglesFromPositions(n, pos);
+    BVH bvh(&tris, sah != 0, threads);
+    std::memcpy(out_list, bvh.list.data(), bvh.list.size() * 4);
+    std::memcpy(out_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(FlatNode));
+    if (stats) {
+        stats[0] = bvh.numTotalSplits(); stats[1] = bvh.numBadSplits(); stats[2] = bvh.depth; stats[3] = bvh.trueDepth();
+        stats[4] = (int64_t)(bvh.buildMillis * 1000.0); stats[5] = (int64_t)(bvh.flattenMillis * 1000.0);
+    }
+    return (int)bvh.nodes.size();
+}
+
+void pth_camera_make(const float eye[3], const float fwd[3], const float up[3], float fov, float nearD, float farD, int width, int height,
+                     ptgpu_camera* out) {
+    CameraControls cam(Vec3f(eye[0], eye[1], eye[2]), Vec3f(fwd[0], fwd[1], fwd[2]), Vec3f(up[0], up[1], up[2]), fov, nearD, farD);
+    // exactly the product tracePath forms per sample (reference src/PathTraceRenderer.cpp:244-248), hoisted to once per render
+    Mat4f projection = Mat4f::fitToView(Vec2f(-1, -1), Vec2f(2, 2), Vec2f(Vec2i(width, height))) * cam.getCameraToClip();
+    Mat4f invP = (projection * cam.getWorldToCamera()).inverted();
+    std::memcpy(out->invP, invP.m, 64);
+    Vec3f f = cam.getForward(), c0 = cam.getOrientation().getCol(0), c1 = cam.getOrientation().getCol(1);
+    std::memcpy(out->forward, &f, 12); std::memcpy(out->orient_col0, &c0, 12); std::memcpy(out->orient_col1, &c1, 12);
+    out->far_ = cam.getFar();
+}
+
+void pth_light_make(const float pos[3], const float orient_cols[9], const float size[2], const float E[3], float intensity, ptgpu_light* out) {
+    AreaLight l(Vec3f(E[0], E[1], E[2]), Vec2f(size[0], size[1]), intensity);
+    Mat3f R;
+    std::memcpy(R.m, orient_cols, 36);
+    l.setOrientation(R);
+    l.setPosition(Vec3f(pos[0], pos[1], pos[2]));
+    l.updatePower();
+    *out = l.toPod();
+}
+
+// AreaLight::sample through the host class, RNG seeded with (k0..k3)
+void pth_light_sample(const ptgpu_light* pod, int base, int bounce, const uint32_t k[4], int disk, float* pdf, float p[3]) {
+    AreaLight l(Vec3f(pod->E[0], pod->E[1], pod->E[2]), Vec2f(pod->size[0], pod->size[1]), pod->intensity);
+    Mat4f X;
+    std::memcpy(X.m, pod->xform, 64);
+    l.setOrientation(X.getXYZ());
+    l.setPosition(X.getCol(3).getXYZ());
+    Random R(k[0], k[1], k[2], k[3]);
+    Vec3f P;
+    if (disk) l.sampleDisk(*pdf, P, base, bounce, R); else l.sample(*pdf, P, base, bounce, R);
+    std::memcpy(p, &P, 12);
+}
+
+void pth_map_to_disk(float a, float b, float* x, float* y) { mapToDisk(a, b, *x, *y); }
+void pth_form_basis(const float n[3], float out9[9]) { Mat3f R = formBasis(Vec3f(n[0], n[1], n[2])); std::memcpy(out9, R.m, 36); }
+float pth_sobol_sample(uint64_t index, uint32_t dim, uint32_t scramble) { return sobol::sample(index, dim, scramble); }
+uint32_t pth_random_u32(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t draw) {
+    Random R(k0, k1, k2, k3);
+    uint32_t v = 0;
+    for (uint32_t i = 0; i <= draw; ++i) v = R.getU32();
+    return v;
+}
+void pth_md5(const void* data, uint64_t len, char out33[33]) { std::memcpy(out33, md5Hex(data, len).c_str(), 33); }
+
+// ---- RayTracer over a mesh file ----
+int pth_rt_open(const char* mesh_path, int sah, void** out) {
+    return guarded([&] {
+        auto box = std::make_unique<TracerBox>();
+        std::string err;
+        box->mesh = importMesh(mesh_path, &err);
+        if (!box->mesh) throw std::runtime_error(err);
+        trianglesFromMesh(*box->mesh, box->tris);
+        box->rt.constructHierarchy(box->tris, sah != 0);
+        *out = box.release();
+    });
+}
+void pth_rt_close(void* h) { delete static_cast<TracerBox*>(h); }
+int pth_rt_counts(void* h, int32_t out[4]) {
+    TracerBox* b = static_cast<TracerBox*>(h);
+    out[0] = (int32_t)b->tris.size(); out[1] = (int32_t)b->rt.bvh.nodes.size(); out[2] = (int32_t)b->rt.bvh.list.size(); out[3] = b->rt.bvh.depth;
+    return 0;
+}
+int pth_rt_get_bvh(void* h, int32_t* out_list, void* out_nodes) {
+    TracerBox* b = static_cast<TracerBox*>(h);
+    std::memcpy(out_list, b->rt.bvh.list.data(), b->rt.bvh.list.size() * 4);
+    std::memcpy(out_nodes, b->rt.bvh.nodes.data(), b->rt.bvh.nodes.size() * sizeof(FlatNode));
+    return 0;
+}
+int pth_rt_save_hierarchy(void* h, const char* path) { return guarded([&] { auto* b = static_cast<TracerBox*>(h); b->rt.saveHierarchy(path, b->tris); }); }
+int pth_rt_load_hierarchy(void* h, const char* path) { return guarded([&] { auto* b = static_cast<TracerBox*>(h); b->rt.loadHierarchy(path, b->tris); }); }
+int pth_rt_mesh_md5(void* h, char out33[33]) {
+    TracerBox* b = static_cast<TracerBox*>(h);
+    std::vector<Vec3f> p;
+    for (int i = 0; i < b->mesh->numVertices(); ++i) p.push_back(b->mesh->vertex(i).p);
+    std::memcpy(out33, RayTracer::computeMD5(p).c_str(), 33);
+    return 0;
+}
+// RayTracer::raycast for n rays; single != 0 calls raycast() once per ray (the reference's signature), else raycastBatch()
+int pth_rt_raycast(void* h, const float* orig, const float* dir, int64_t n, int occlusion, int single, int32_t* id, float* t, float* u,
+                   float* v, float* point) {
+    return guarded([&] {
+        TracerBox* b = static_cast<TracerBox*>(h);
+        std::vector<RaycastResult> res(n);
+        const Vec3f* O = reinterpret_cast<const Vec3f*>(orig);
+        const Vec3f* D = reinterpret_cast<const Vec3f*>(dir);
+        if (single) for (int64_t i = 0; i < n; ++i) res[i] = b->rt.raycast(O[i], D[i], occlusion != 0);
+        else b->rt.raycastBatch(O, D, (size_t)n, occlusion != 0, res.data());
+        for (int64_t i = 0; i < n; ++i) {
+            id[i] = res[i].tri ? (int32_t)(res[i].tri - b->tris.data()) : -1;
+            t[i] = res[i].t; u[i] = res[i].u; v[i] = res[i].v;
+            if (point) std::memcpy(point + i * 3, &res[i].point, 12);
+        }
+    });
+}
+int pth_rt_ray_count(void* h) { return static_cast<TracerBox*>(h)->rt.getRayCount(); }
+void pth_rt_reset_ray_counter(void* h) { static_cast<TracerBox*>(h)->rt.resetRayCounter(); }
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""ctypes binding of libpthost.so: the C++ host mirror of the reference's classes (FW::BVH, RayTracer, AreaLight,
+CameraControls, PathTraceRenderer) as exposed by host/hostapi.cpp.  libpthost.so links libptgpu.so; functions that trace
+rays or render need a GPU, the builders and samplers do not."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .capi import FLATNODE_DTYPE, Camera, Light, load_library
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpthost.so")
+_P = C.c_void_p
+_lib = None
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        load_library()  # libptgpu.so first: fail loudly if the HIP extension is missing
+        if not os.path.exists(LIB_PATH):
+            raise HostError("%s is not built: run __graft_entry__.build()" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.pth_last_error.restype = C.c_char_p
+        L.pth_woop_from_positions.argtypes = [C.c_int, _P, _P]
+        L.pth_bvh_build.restype = C.c_int
+        L.pth_bvh_build.argtypes = [C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]
+        L.pth_camera_make.argtypes = [_P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(Camera)]
+        L.pth_light_make.argtypes = [_P, _P, _P, _P, C.c_float, C.POINTER(Light)]
+        L.pth_light_sample.argtypes = [C.POINTER(Light), C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_float), _P]
+        L.pth_map_to_disk.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.pth_form_basis.argtypes = [_P, _P]
+        L.pth_sobol_sample.restype = C.c_float
+        L.pth_sobol_sample.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.pth_random_u32.restype = C.c_uint32
+        L.pth_random_u32.argtypes = [C.c_uint32] * 5
+        L.pth_md5.argtypes = [_P, C.c_uint64, _P]
+        L.pth_rt_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(_P)]
+        L.pth_rt_close.argtypes = [_P]
+        L.pth_rt_counts.argtypes = [_P, _P]
+        L.pth_rt_get_bvh.argtypes = [_P, _P, _P]
+        L.pth_rt_save_hierarchy.argtypes = [_P, C.c_char_p]
+        L.pth_rt_load_hierarchy.argtypes = [_P, C.c_char_p]
+        L.pth_rt_mesh_md5.argtypes = [_P, _P]
+        L.pth_rt_raycast.argtypes = [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P]
+        L.pth_rt_ray_count.argtypes = [_P]
+        L.pth_rt_reset_ray_counter.argtypes = [_P]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _check(rc):
+    if rc != 0:
+        raise HostError(lib().pth_last_error().decode())
+
+
+def woop_from_positions(pos):
+    """tri_data for every triangle (reference src/RTTriangle.hpp:14-20) -> [n,12] rows (M | N)."""
+    pos = _f32(pos).reshape(-1, 9)
+    out = np.empty((pos.shape[0], 12), np.float32)
+    lib().pth_woop_from_positions(pos.shape[0], pos.ctypes.data, out.ctypes.data)
+    return out
+
+
+def bvh_build(pos, sah=True, threads=0):
+    """FW::BVH(triangles, sah) on the host (multi-threaded over subtrees). Returns (nodes, list, stats)."""
+    pos = _f32(pos).reshape(-1, 9)
+    n = pos.shape[0]
+    nodes = np.zeros(max(2 * n, 1), dtype=FLATNODE_DTYPE)
+    lst = np.zeros(max(n, 1), dtype=np.int32)
+    st = np.zeros(6, dtype=np.int64)
+    cnt = lib().pth_bvh_build(n, pos.ctypes.data, int(bool(sah)), threads, lst.ctypes.data, nodes.ctypes.data, st.ctypes.data)
+    stats = dict(total_splits=int(st[0]), bad_splits=int(st[1]), depth_field=int(st[2]), true_depth=int(st[3]),
+                 build_ms=st[4] / 1000.0, flatten_ms=st[5] / 1000.0, nodes=int(cnt))
+    return nodes[:cnt].copy(), lst[:n].copy(), stats
+
+
+def make_camera(eye=(0.0, 0.0, 0.48), forward=(0.0, -0.1, -1.0), up=(0.0, 1.0, 0.0), fov_deg=70.0, near=0.001, far=3.0,
+                width=512, height=512):
+    """Camera POD from FW::CameraControls; defaults = the probe camera of SURVEY.md 8d config C1."""
+    cam = Camera()
+    e, f, u = _f32(eye), _f32(forward), _f32(up)
+    lib().pth_camera_make(e.ctypes.data, f.ctypes.data, u.ctypes.data, fov_deg, near, far, width, height, C.byref(cam))
+    return cam
+
+
+def make_light(position=(0.0, 0.9, 0.2), col0=(1.0, 0.0, 0.0), col1=(0.0, 0.0, -1.0), col2=(0.0, 1.0, 0.0), size=(0.25, 0.25),
+               E=(100.0, 100.0, 100.0), intensity=1.0):
+    """AreaLight POD from FW::AreaLight. Default: the SURVEY.md C1 light, normal = -col2 = straight down."""
+    L = Light()
+    p, o, s, e = _f32(position), _f32([col0, col1, col2]).reshape(-1), _f32(size), _f32(E)
+    lib().pth_light_make(p.ctypes.data, o.ctypes.data, s.ctypes.data, e.ctypes.data, intensity, C.byref(L))
+    return L
+
+
+def light_sample(light, base, bounce, key, disk=False):
+    k = np.asarray(key, np.uint32)
+    pdf, p = C.c_float(), np.empty(3, np.float32)
+    lib().pth_light_sample(C.byref(light), base, bounce, k.ctypes.data, int(disk), C.byref(pdf), p.ctypes.data)
+    return pdf.value, p
+
+
+def md5_hex(data):
+    buf = np.ascontiguousarray(data)
+    out = C.create_string_buffer(33)
+    lib().pth_md5(buf.ctypes.data, buf.nbytes, out)
+    return out.value.decode()
+
+
+class HostRayTracer:
+    """FW::RayTracer over a mesh file: App::constructTracer's triangle array + constructHierarchy."""
+
+    def __init__(self, mesh_path, sah=True):
+        h = _P()
+        _check(lib().pth_rt_open(mesh_path.encode(), int(sah), C.byref(h)))
+        self.h = h
+        c = np.zeros(4, np.int32)
+        lib().pth_rt_counts(h, c.ctypes.data)
+        self.num_tris, self.num_nodes, self.list_size, self.depth_field = (int(x) for x in c)
+
+    def close(self):
+        if self.h:
+            lib().pth_rt_close(self.h)
+            self.h = None
+
+    def bvh(self):
+        c = np.zeros(4, np.int32)
+        lib().pth_rt_counts(self.h, c.ctypes.data)
+        nodes, lst = np.zeros(int(c[1]), FLATNODE_DTYPE), np.zeros(int(c[2]), np.int32)
+        lib().pth_rt_get_bvh(self.h, lst.ctypes.data, nodes.ctypes.data)
+        return nodes, lst
+
+    def save_hierarchy(self, path):
+        _check(lib().pth_rt_save_hierarchy(self.h, path.encode()))
+
+    def load_hierarchy(self, path):
+        _check(lib().pth_rt_load_hierarchy(self.h, path.encode()))
+
+    def mesh_md5(self):
+        out = C.create_string_buffer(33)
+        lib().pth_rt_mesh_md5(self.h, out)
+        return out.value.decode()
+
+    def raycast(self, orig, direction, occlusion=False, single=False):
+        o, d = _f32(orig).reshape(-1, 3), _f32(direction).reshape(-1, 3)
+        n = o.shape[0]
+        out = dict(id=np.empty(n, np.int32), t=np.empty(n, np.float32), u=np.empty(n, np.float32), v=np.empty(n, np.float32),
+                   point=np.empty((n, 3), np.float32))
+        _check(lib().pth_rt_raycast(self.h, o.ctypes.data, d.ctypes.data, n, int(occlusion), int(single), out["id"].ctypes.data,
+                                    out["t"].ctypes.data, out["u"].ctypes.data, out["v"].ctypes.data, out["point"].ctypes.data))
+        return out
+
+    def ray_count(self):
+        return lib().pth_rt_ray_count(self.h)
+
+    def reset_ray_counter(self):
+        lib().pth_rt_reset_ray_counter(self.h)

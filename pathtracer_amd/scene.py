@@ -67,70 +67,17 @@ def mesh_materials(mesh, textured=False, texture_index=None):
     return out
 
 
-# ---- camera: FW CameraControls / Mat4f conventions (column-major, GL clip space) in float32 ----
-def _f(x):
-    return np.float32(x)
+# ---- camera / light PODs come from the C++ host classes (FW::CameraControls, FW::AreaLight) ----
+def make_camera(**kw):
+    """Camera POD; defaults = the probe camera of SURVEY.md 8d config C1 (see hostapi.make_camera)."""
+    from . import hostapi
+    return hostapi.make_camera(**kw)
 
 
-def _normalize(v):
-    v = np.asarray(v, dtype=np.float32)
-    return (v * (_f(1.0) / np.sqrt(np.dot(v, v), dtype=np.float32))).astype(np.float32)
-
-
-def camera_matrices(eye, forward, up, fov_deg, near, far, width, height):
-    """Returns (worldToCamera, cameraToClip, fitToView, orientation) as float32 4x4/3x3 (row-major numpy)."""
-    eye = np.asarray(eye, np.float32)
-    z = -_normalize(forward)
-    x = _normalize(np.cross(np.asarray(up, np.float32), z).astype(np.float32))
-    y = _normalize(np.cross(z, x).astype(np.float32))
-    orient = np.stack([x, y, z], axis=1).astype(np.float32)  # columns
-    w2c = np.eye(4, dtype=np.float32)
-    w2c[:3, :3] = orient.T
-    w2c[:3, 3] = -(orient.T @ eye)
-    f = _f(1.0) / np.tan(_f(fov_deg) * _f(np.pi) / _f(360.0), dtype=np.float32)
-    d = _f(1.0) / (_f(near) - _f(far))
-    c2c = np.zeros((4, 4), np.float32)
-    c2c[0, 0] = f
-    c2c[1, 1] = f
-    c2c[2, 2] = (_f(near) + _f(far)) * d
-    c2c[2, 3] = _f(2.0) * _f(near) * _f(far) * d
-    c2c[3, 2] = -1.0
-    # Mat4f::fitToView(pos=(-1,-1), size=(2,2), viewSize): uniform fit of the [-1,1]^2 square into the viewport
-    vs = np.array([width, height], np.float32)
-    sc = (np.min(vs / _f(2.0)) / vs * _f(2.0)).astype(np.float32)
-    ftv = np.diag([sc[0], sc[1], _f(1.0), _f(1.0)]).astype(np.float32)
-    return w2c, c2c, ftv, orient
-
-
-def make_camera(eye=(0.0, 0.0, 0.48), forward=(0.0, -0.1, -1.0), up=(0.0, 1.0, 0.0), fov_deg=70.0, near=0.001, far=3.0,
-                width=512, height=512):
-    """Camera POD; defaults = the probe camera of SURVEY.md 8d config C1."""
-    w2c, c2c, ftv, orient = camera_matrices(eye, forward, up, fov_deg, near, far, width, height)
-    proj = (ftv @ c2c).astype(np.float32)
-    m = (proj @ w2c).astype(np.float32)
-    invp = np.linalg.inv(m.astype(np.float64)).astype(np.float32)
-    cam = Camera()
-    cam.invP[:] = invp.T.reshape(-1)  # column-major
-    cam.forward[:] = _normalize(forward)
-    cam.orient_col0[:] = orient[:, 0]
-    cam.orient_col1[:] = orient[:, 1]
-    cam.far_ = far
-    return cam
-
-
-def make_light(position=(0.0, 0.9, 0.2), col0=(1.0, 0.0, 0.0), col1=(0.0, 0.0, -1.0), col2=(0.0, 1.0, 0.0), size=(0.25, 0.25),
-               E=(100.0, 100.0, 100.0), intensity=1.0):
-    """AreaLight POD (reference src/AreaLight.hpp). Default: SURVEY.md C1 light, normal = -col2 = straight down."""
-    L = Light()
-    x = np.zeros((4, 4), np.float32)
-    x[:3, 0], x[:3, 1], x[:3, 2], x[:3, 3], x[3, 3] = col0, col1, col2, position, 1.0
-    L.xform[:] = x.T.reshape(-1)
-    L.size[:] = size
-    L.E[:] = E
-    L.intensity = intensity
-    e = np.asarray(E, np.float32)
-    L.power = float(_f(4.0) * _f(size[0]) * _f(size[1]) * np.sqrt(np.dot(e, e), dtype=np.float32) * _f(intensity))
-    return L
+def make_light(**kw):
+    """AreaLight POD; default = the SURVEY.md C1 light (see hostapi.make_light)."""
+    from . import hostapi
+    return hostapi.make_light(**kw)
 
 
 def make_params(width=512, height=512, bounces=-1, num_aa_rays=16, sobol_block=True, bilinear=True, normal_mapped=False,
