@@ -62,7 +62,10 @@ def main():
 
     sd, bvh_stats = build_head_scene()
     ctx = capi.Context(local_rank)
-    stream = torch.cuda.current_stream(dev)
+    # a real (non-null) stream shared by the library's launches and torch's events: torch.cuda.Event only sees the stream
+    # it is recorded on, and a NULL handle would make the library fall back to its own stream
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     gscene = capi.Scene(ctx, sd)
     # rank r renders tile set r of the N-times-taller frame: same camera, its own band => identical per-rank work

@@ -46,11 +46,11 @@ def test_single_ray_signature(host_rt, head, oracle):
 
 
 def test_hierarchy_cache_roundtrip(host_rt, head, oracle, tmp_path):
-    """saveHierarchy / loadHierarchy (reference src/RayTracer.cpp:74-165): 37-byte unpadded node records; a reloaded
+    """saveHierarchy / loadHierarchy (reference src/RayTracer.cpp:74-165): 41-byte unpadded node records (2 x Vec3f, 3 x int32, 1-byte bool, int32); a reloaded
     hierarchy traces identically."""
     path = str(tmp_path / ("Hierarchy-%s-sah-x64.bin" % host_rt.mesh_md5()))
     host_rt.save_hierarchy(path)
-    assert os.path.getsize(path) == 4 + 4 * 17692 + 4 + 37 * 15619 + 4
+    assert os.path.getsize(path) == 4 + 4 * 17692 + 4 + 41 * 15619 + 4
     raw = open(path, "rb").read()
     assert np.frombuffer(raw, "<i4", 1)[0] == 17692
     assert np.array_equal(np.frombuffer(raw, "<i4", 17692, 4), head["list"])
