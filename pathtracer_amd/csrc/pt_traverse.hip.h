@@ -213,4 +213,133 @@ __device__ __forceinline__ HitRec traverse(const TravScene& S, F3 o, F3 d, uint2
     return best;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Step-wise traverser: the same traversal as traverse() above, cut into single steps so that a wave never waits on
+// its slowest lane inside a phase.  Node records and triangle records are both 64 B, so ONE 4 x dwordx4 fetch per step
+// serves every lane whatever it is doing (visiting an interior node or testing one triangle); the two arithmetic
+// bodies then run under their own exec masks.  A lane that finishes can be handed a new ray by its kernel between two
+// steps (persistent waves with refill).  Hit records are identical to traverse(): same tests, same order.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool ALPHA, bool COUNT, int NLDS, bool OVF>
+struct Trav {
+    F3 o, d, inv;
+    uint32_t signbits;
+    float tmin, umin, vmin;
+    int pmin;
+    int cur;
+    bool alive, anyhit;
+    LaneStack<NLDS, OVF> st;
+    uint32_t n_nodes, n_tris;
+
+    __device__ __forceinline__ void reset_counts() { n_nodes = 0; n_tris = 0; }
+
+    __device__ __forceinline__ void begin(const TravScene& S, F3 o_, F3 d_, bool anyhit_, uint2* lds_lane) {
+        o = o_; d = d_; anyhit = anyhit_;
+        tmin = 1.0f; umin = 0.0f; vmin = 0.0f; pmin = -1;
+        inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+        signbits = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
+        st.lds = lds_lane;
+        st.sp = 0;
+        cur = S.root_ref;
+        alive = false;
+        if (S.list_size > 0) {
+            bool ok; float te;
+            slab(sx ? S.root_bmax[0] : S.root_bmin[0], sy ? S.root_bmax[1] : S.root_bmin[1], sz ? S.root_bmax[2] : S.root_bmin[2],
+                 sx ? S.root_bmin[0] : S.root_bmax[0], sy ? S.root_bmin[1] : S.root_bmax[1], sz ? S.root_bmin[2] : S.root_bmax[2],
+                 o, inv, ok, te);
+            alive = ok && (te < tmin);
+            if (COUNT) n_nodes += 1;
+        }
+    }
+
+    __device__ __forceinline__ void pop_next() {
+        alive = false;
+        while (st.sp > 0) {
+            uint2 e = st.pop();
+            if (COUNT) n_nodes += 1;
+            if (__uint_as_float(e.y) < tmin) { cur = (int)e.x; alive = true; break; }
+        }
+    }
+
+    // one step for a lane with alive == true
+    __device__ __forceinline__ void step(const TravScene& S) {
+        const float4* rp = (cur >= 0) ? (S.inner + (size_t)cur * 4) : (S.tris + (size_t)(~cur) * 4);
+        float4 a = ldg4(rp), b = ldg4(rp + 1), c = ldg4(rp + 2), m = ldg4(rp + 3);
+        const bool sx = (signbits & 1u) != 0u, sy = (signbits & 2u) != 0u, sz = (signbits & 4u) != 0u;
+        if (cur >= 0) {
+            bool okL, okR; float teL, teR;
+            slab(sx ? a.w : a.x, sy ? b.x : a.y, sz ? b.y : a.z, sx ? a.x : a.w, sy ? a.y : b.x, sz ? a.z : b.y, o, inv, okL, teL);
+            slab(sx ? c.y : b.z, sy ? c.z : b.w, sz ? c.w : c.x, sx ? b.z : c.y, sy ? b.w : c.z, sz ? c.x : c.w, o, inv, okR, teR);
+            int refL = __float_as_int(m.x), refR = __float_as_int(m.y);
+            bool rightFirst = ((signbits >> __float_as_int(m.z)) & 1u) != 0u;
+            int refN = rightFirst ? refR : refL, refF = rightFirst ? refL : refR;
+            bool okN = rightFirst ? okR : okL, okF = rightFirst ? okL : okR;
+            float teN = rightFirst ? teR : teL, teF = rightFirst ? teL : teR;
+            bool passN = okN && (teN < tmin);
+            bool passF = okF && (teF < tmin);
+            if (COUNT) {
+                n_nodes += 1;
+                st.push(refF, passF ? teF : __uint_as_float(0x7f800000u));
+                passF = false;
+            }
+            if (passN) {
+                if (passF) st.push(refF, teF);
+                cur = refN;
+            } else if (passF) {
+                cur = refF;
+            } else {
+                pop_next();
+            }
+        } else {
+            if (COUNT) n_tris += 1;
+            float ox = (a.x * o.x + a.y * o.y + a.z * o.z) + a.w;
+            float oy = (b.x * o.x + b.y * o.y + b.z * o.z) + b.w;
+            float oz = (c.x * o.x + c.y * o.y + c.z * o.z) + c.w;
+            float dx = a.x * d.x + a.y * d.y + a.z * d.z;
+            float dy = b.x * d.x + b.y * d.y + b.z * d.z;
+            float dz = c.x * d.x + c.y * d.y + c.z * d.z;
+            float t = -oz / dz;
+            float u = ox + dx * t;
+            float v = oy + dy * t;
+            bool done = false;
+            if (u > 0.0f && v > 0.0f && u + v < 1.0f) {
+                bool keep = true;
+                if (ALPHA) {
+                    int atex = __float_as_int(m.z);
+                    if (atex >= 0) {
+                        const float* tc = S.uv + (size_t)__float_as_int(m.x) * 6;
+                        F2 uv = (1 - u - v) * ld2(tc) + u * ld2(tc + 2) + v * ld2(tc + 4);
+                        DevTexture tx = S.textures[atex];
+                        int x = (int)((uv.x - floorf(uv.x)) * tx.width);
+                        int y = (int)((uv.y - floorf(uv.y)) * tx.height);
+                        x = x < 0 ? 0 : (x > tx.width - 1 ? tx.width - 1 : x);
+                        y = y < 0 ? 0 : (y > tx.height - 1 ? tx.height - 1 : y);
+                        float alpha = (float)tx.rgba[((size_t)y * tx.width + x) * 4 + 1] / 255.0f;
+                        keep = !(alpha < 0.5f);
+                    }
+                }
+                if (keep && t > 0.0f && t < tmin) {
+                    pmin = ~cur; tmin = t; umin = u; vmin = v;
+                    done = anyhit;
+                }
+            }
+            if (done) alive = false;
+            else if (__float_as_int(m.y) != 0) cur -= 1;  // next record of this leaf: ~(pos + 1) == cur - 1
+            else pop_next();
+        }
+    }
+
+    __device__ __forceinline__ HitRec result(const TravScene& S) const {
+        HitRec h;
+        h.id = -1; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f;
+        if (pmin >= 0) {
+            h.id = __float_as_int(S.tris[(size_t)pmin * 4 + 3].x);
+            h.t = tmin; h.u = umin; h.v = vmin;
+        }
+        return h;
+    }
+};
+
 }  // namespace ptd

@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -42,6 +43,7 @@ struct ptgpu_context {
     hipStream_t stream = nullptr;
     bool count = false;
     unsigned long long* d_counters = nullptr;  // rays, node visits, triangle tests
+    int num_cu = 256;
 };
 
 struct ptgpu_scene {
@@ -79,6 +81,7 @@ extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
     c->stream = c->own_stream;
     HIP_TRY(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out_ctx = c;
     return PTGPU_OK;
 }
@@ -366,21 +369,162 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast(ptd::TravScene S, const fl
     }
 }
 
+// Step-wise variant, one ray per lane for the lane's whole life (no refill).
+template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
+__global__ __launch_bounds__(RC_BLOCK) void k_raycast_step(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
+                                                           long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
+                                                           float* __restrict__ out_u, float* __restrict__ out_v, unsigned long long* counters) {
+    __shared__ uint2 lds_stack[RC_BLOCK / 64][NLDS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
+    ptd::Trav<ALPHA, COUNT, NLDS, OVF> tr;
+    tr.reset_counts();
+    tr.alive = false;
+    if (i < n) {
+        tr.begin(S, ptd::ld3(orig + i * 3), ptd::ld3(dir + i * 3), ANYHIT, &lds_stack[wave][0][lane]);
+        while (tr.alive) tr.step(S);
+        ptd::HitRec h = tr.result(S);
+        if (out_id) out_id[i] = h.id;
+        if (out_t) out_t[i] = h.t;
+        if (out_u) out_u[i] = h.u;
+        if (out_v) out_v[i] = h.v;
+    }
+    if (COUNT) {
+        atomicAdd(&counters[1], (unsigned long long)tr.n_nodes);
+        atomicAdd(&counters[2], (unsigned long long)tr.n_tris);
+    }
+}
+
+// Long-lived waves with refill: wave w of W owns one chunk of RC_CHUNK consecutive rays out of every W consecutive chunks and hands
+// fresh rays to its idle lanes in batches (ballot + prefix count), so lanes do not idle while the wave's slowest ray
+// finishes.  The chunk stride is static: pulling chunks from a shared cursor (one word, or eight sharded ones) was
+// measured 1.8-2.2x slower on the configs[1] frame.  The grid is a small multiple of what is resident at once, so the
+// dispatcher still evens out cheap and expensive image regions.  Which lane traces which ray never affects a result.
+// Exit: the wave's chunk index has passed the last chunk and no lane holds a ray.
+constexpr int RC_CHUNK = 64;
+template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
+__global__ __launch_bounds__(RC_BLOCK) void k_raycast_persist(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
+                                                              long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
+                                                              float* __restrict__ out_u, float* __restrict__ out_v,
+                                                              unsigned long long* counters, int refill_threshold) {
+    __shared__ uint2 lds_stack[RC_BLOCK / 64][NLDS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2* lds_lane = &lds_stack[wave][0][lane];
+    ptd::Trav<ALPHA, COUNT, NLDS, OVF> tr;
+    tr.reset_counts();
+    tr.alive = false;
+    long long ray = -1;           // ray this lane currently owns
+    long long next = 0, end = 0;  // wave-uniform: unassigned part of the wave's current chunk
+    const long long total_waves = (long long)gridDim.x * (RC_BLOCK / 64);
+    const long long wave_id = (long long)blockIdx.x * (RC_BLOCK / 64) + wave;
+    long long round = -1;  // advanced before first use
+    bool exhausted = false;       // wave-uniform
+    for (;;) {
+        // Retire finished rays and hand out new ones in batches: doing it the moment any single lane finishes would add
+        // two dependent memory round trips (hit record out, ray in) to nearly every step of the whole wave.
+        const unsigned long long running = __ballot(tr.alive);
+        const int idle = 64 - __popcll(running);
+        if (idle >= refill_threshold || running == 0ull) {
+            if (ray >= 0 && !tr.alive) {
+                ptd::HitRec h = tr.result(S);
+                if (out_id) out_id[ray] = h.id;
+                if (out_t) out_t[ray] = h.t;
+                if (out_u) out_u[ray] = h.u;
+                if (out_v) out_v[ray] = h.v;
+                ray = -1;
+            }
+            unsigned long long need = __ballot(ray < 0);
+            while (need != 0ull && !exhausted) {
+                if (next >= end) {
+                    // round r hands this wave chunk r*W + (w + 997 r) mod W: rotating the assignment every round keeps one wave
+                    // from drawing the same image columns (all cheap or all expensive) in every round
+                    round += 1;
+                    const long long base = (round * total_waves + (wave_id + round * 997) % total_waves) * RC_CHUNK;
+                    if (base >= n) { exhausted = true; break; }
+                    next = base;
+                    end = next + RC_CHUNK < n ? next + RC_CHUNK : n;
+                }
+                int avail = (int)(end - next);
+                int rank = __popcll(need & ((1ull << lane) - 1ull));  // position of this lane among the lanes that need a ray
+                if ((ray < 0) && (rank < avail)) {
+                    ray = next + rank;
+                    tr.begin(S, ptd::ld3(orig + ray * 3), ptd::ld3(dir + ray * 3), ANYHIT, lds_lane);
+                }
+                int taken = __popcll(need) < avail ? __popcll(need) : avail;
+                next += taken;
+                need = __ballot(ray < 0);
+            }
+        }
+        if (__ballot(ray >= 0) == 0ull) break;  // nothing left in this wave (only reachable once exhausted)
+        if (tr.alive) tr.step(S);
+    }
+    if (COUNT) {
+        atomicAdd(&counters[1], (unsigned long long)tr.n_nodes);
+        atomicAdd(&counters[2], (unsigned long long)tr.n_tris);
+    }
+}
+
 __global__ void k_add_rays(unsigned long long* counters, unsigned long long n) {
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], n);
 }
 
-template <bool ANYHIT, bool ALPHA, bool COUNT>
-static void launch_raycast2(ptgpu_scene* s, bool ovf, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
-    dim3 grid((unsigned)((n + RC_BLOCK - 1) / RC_BLOCK)), block(RC_BLOCK);
-    hipStream_t st = s->ctx->stream;
-    if (ovf) hipLaunchKernelGGL((k_raycast<ANYHIT, ALPHA, COUNT, true>), grid, block, 0, st, s->trav, o, d, n, id, t, u, v, s->ctx->d_counters);
-    else hipLaunchKernelGGL((k_raycast<ANYHIT, ALPHA, COUNT, false>), grid, block, 0, st, s->trav, o, d, n, id, t, u, v, s->ctx->d_counters);
+// Kernel selection.  Defaults are the measured-best variant; PTGPU_RAYCAST_IMPL (0 = while-while, 1 = step-wise,
+// 2 = persistent step-wise with refill) and PTGPU_RAYCAST_NLDS (8 / 16 / 24 LDS stack entries per lane) exist for A/B
+// timing in one process (read at every launch).  Every variant produces identical hit records.
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
-template <bool ANYHIT, bool ALPHA>
-static void launch_raycast1(ptgpu_scene* s, bool count, bool ovf, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
-    if (count) launch_raycast2<ANYHIT, ALPHA, true>(s, ovf, o, d, n, id, t, u, v);
-    else launch_raycast2<ANYHIT, ALPHA, false>(s, ovf, o, d, n, id, t, u, v);
+struct RcConfig { int impl, nlds; };
+static RcConfig rc_config() {
+    RcConfig c = {env_int("PTGPU_RAYCAST_IMPL", 1), env_int("PTGPU_RAYCAST_NLDS", 24)};
+    return c;
+}
+
+template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
+static int launch_rc_impl(ptgpu_scene* s, int impl, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
+    ptgpu_context* c = s->ctx;
+    hipStream_t st = c->stream;
+    dim3 block(RC_BLOCK);
+    if (impl == 2) {
+        long long want = (n + RC_CHUNK - 1) / RC_CHUNK;  // no more waves than chunks
+        long long blocks = (want + (RC_BLOCK / 64) - 1) / (RC_BLOCK / 64);
+        // a small multiple of the blocks resident at once (LDS-limited): long-lived waves, dispatcher-level balancing
+        static int per_cu = 0;
+        if (per_cu == 0) {
+            int v = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>, RC_BLOCK, 0) != hipSuccess || v < 1) v = 1;
+            per_cu = v;
+        }
+        long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_RAYCAST_OVERSUB", 2);
+        if (blocks > resident) blocks = resident;
+        hipLaunchKernelGGL((k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>), dim3((unsigned)blocks), block, 0, st, s->trav, o, d, n, id, t,
+                           u, v, c->d_counters, env_int("PTGPU_RAYCAST_REFILL", 32));
+    } else {
+        dim3 grid((unsigned)((n + RC_BLOCK - 1) / RC_BLOCK));
+        if (impl == 1)
+            hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, NLDS, OVF>), grid, block, 0, st, s->trav, o, d, n, id, t, u, v, c->d_counters);
+        else if constexpr (NLDS == RC_NLDS)
+            hipLaunchKernelGGL((k_raycast<ANYHIT, ALPHA, COUNT, OVF>), grid, block, 0, st, s->trav, o, d, n, id, t, u, v, c->d_counters);
+        else
+            return fail(PTGPU_E_UNSUPPORTED, "while-while kernel is only built with %d LDS stack entries", RC_NLDS);
+    }
+    return PTGPU_OK;
+}
+
+template <bool ANYHIT, bool ALPHA, bool COUNT>
+static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
+    RcConfig cfg = rc_config();
+    // stack occupancy <= depth - 1 (one far sibling per ancestor level); the counting variant pushes every far child as well
+    const int need = s->depth - 1;
+    if constexpr (!ALPHA && !COUNT) {  // tuning variants are only built for the plain kernels
+        if (cfg.nlds == 8) return need > 8 ? launch_rc_impl<ANYHIT, ALPHA, COUNT, 8, true>(s, cfg.impl, o, d, n, id, t, u, v)
+                                           : launch_rc_impl<ANYHIT, ALPHA, COUNT, 8, false>(s, cfg.impl, o, d, n, id, t, u, v);
+        if (cfg.nlds == 24) return need > 24 ? launch_rc_impl<ANYHIT, ALPHA, COUNT, 24, true>(s, cfg.impl, o, d, n, id, t, u, v)
+                                             : launch_rc_impl<ANYHIT, ALPHA, COUNT, 24, false>(s, cfg.impl, o, d, n, id, t, u, v);
+    }
+    return need > RC_NLDS ? launch_rc_impl<ANYHIT, ALPHA, COUNT, RC_NLDS, true>(s, cfg.impl, o, d, n, id, t, u, v)
+                          : launch_rc_impl<ANYHIT, ALPHA, COUNT, RC_NLDS, false>(s, cfg.impl, o, d, n, id, t, u, v);
 }
 
 extern "C" int ptgpu_raycast_batch_dev(ptgpu_scene* s, int use_alpha, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
@@ -392,15 +536,19 @@ extern "C" int ptgpu_raycast_batch_dev(ptgpu_scene* s, int use_alpha, const floa
     if ((n + RC_BLOCK - 1) / RC_BLOCK > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large for one launch");
     HIP_TRY(hipSetDevice(s->ctx->device));
     const bool alpha = use_alpha && s->has_alpha, count = s->ctx->count;
-    // stack occupancy <= depth - 1 (one far sibling per ancestor level); counting mode pushes every far child too
-    const bool ovf = (s->depth - 1) > RC_NLDS;
-    if (occlusion) {
-        if (alpha) launch_raycast1<true, true>(s, count, ovf, d_orig, d_dir, n, d_id, d_t, d_u, d_v);
-        else launch_raycast1<true, false>(s, count, ovf, d_orig, d_dir, n, d_id, d_t, d_u, d_v);
-    } else {
-        if (alpha) launch_raycast1<false, true>(s, count, ovf, d_orig, d_dir, n, d_id, d_t, d_u, d_v);
-        else launch_raycast1<false, false>(s, count, ovf, d_orig, d_dir, n, d_id, d_t, d_u, d_v);
+    int rc;
+    const int sel = (occlusion ? 4 : 0) | (alpha ? 2 : 0) | (count ? 1 : 0);
+    switch (sel) {
+        case 0: rc = launch_raycast<false, false, false>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 1: rc = launch_raycast<false, false, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 2: rc = launch_raycast<false, true, false>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 3: rc = launch_raycast<false, true, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 4: rc = launch_raycast<true, false, false>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 5: rc = launch_raycast<true, false, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 6: rc = launch_raycast<true, true, false>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        default: rc = launch_raycast<true, true, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
     }
+    if (rc != PTGPU_OK) return rc;
     hipLaunchKernelGGL(k_add_rays, dim3(1), dim3(64), 0, s->ctx->stream, s->ctx->d_counters, (unsigned long long)n);
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;
