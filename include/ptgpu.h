@@ -172,6 +172,24 @@ int ptgpu_gen_shadow_dev(ptgpu_scene* scene, const ptgpu_light* light, int64_t n
                          const int32_t* d_id, const float* d_t, const float* d_u, const float* d_v,
                          float* d_sh_orig, float* d_sh_dir, int32_t* d_sh_valid);
 
+/* ---- PathTraceRenderer: replaces the worker-thread launch in startPathTracingProcess / checkFinish
+ * (m_launcher.push(pathTraceBlock, ...), src/PathTraceRenderer.cpp:847-852, :906-910) and pathTraceBlock + tracePath
+ * themselves (:663-790, :236-551).  One call = one pass over the 32x32 blocks (row-major block index as :816-841 numbers
+ * them) b = block_begin, block_begin + block_stride, ... < block_end (block_end < 0: all blocks), every block with all its
+ * samples (block area x num_aa_rays), accumulated into accum[height][width][4] exactly as :727-732 (Sobol-block mode) or
+ * :743-787 (Gaussian mode) do: += on the existing contents, samples of a pixel added in the reference's order.  The block
+ * subset is how image tiles are sharded over GPUs: rank r of N passes block_begin = r, block_stride = N.
+ * Per-sample RNG streams are keyed by (block, pass_seed, i, k) (documented deviation from the reference's one sequential
+ * Random per block, which cannot be parallelised); params->pass_seed plays the role of the reference's seed counter.
+ * lights: HOST array.  _dev: d_accum is a DEVICE pointer and the call only enqueues work. */
+int ptgpu_render_pass_dev(ptgpu_scene* scene, const ptgpu_params* params, const ptgpu_camera* cam, const ptgpu_light* lights,
+                          int32_t num_lights, int32_t block_begin, int32_t block_end, int32_t block_stride, float* d_accum);
+int ptgpu_render_pass(ptgpu_scene* scene, const ptgpu_params* params, const ptgpu_camera* cam, const ptgpu_light* lights,
+                      int32_t num_lights, int32_t block_begin, int32_t block_end, int32_t block_stride, float* accum);
+/* PathTraceRenderer::updatePicture (src/PathTraceRenderer.cpp:855-871): out = (pow(rgb / w, 1/2.2), w / w) per pixel, w == 0
+ * pixels pass through undivided.  Both pointers are DEVICE pointers, [height][width][4] floats. */
+int ptgpu_resolve_dev(ptgpu_context* ctx, const float* d_accum, int32_t width, int32_t height, float* d_out_rgba);
+
 #ifdef __cplusplus
 }
 #endif

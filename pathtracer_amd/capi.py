@@ -92,6 +92,9 @@ SIGNATURES = [
     ("ptgpu_raycast_batch_dev", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
     ("ptgpu_gen_primary_dev", C.c_int, [_P, C.POINTER(Camera), C.c_int32, C.c_int32, _P, _P]),
     ("ptgpu_gen_shadow_dev", C.c_int, [_P, C.POINTER(Light), C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("ptgpu_render_pass_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("ptgpu_render_pass", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("ptgpu_resolve_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
 ]
 
 _lib = None
@@ -178,6 +181,21 @@ class Context:
         _check(self.lib.ptgpu_get_counters(self.handle, C.byref(c)))
         return dict(rays=c.rays, node_visits=c.node_visits, tri_tests=c.tri_tests)
 
+    def resolve_dev(self, d_accum, width, height, d_out):
+        _check(self.lib.ptgpu_resolve_dev(self.handle, d_accum, width, height, d_out))
+
+    def resolve(self, accum):
+        """updatePicture on a host accumulation image [h,w,4] -> resolved [h,w,4]."""
+        a = np.ascontiguousarray(accum, dtype=np.float32)
+        h, w = a.shape[:2]
+        d_in, d_out = self.to_device(a), self.malloc(a.nbytes)
+        try:
+            self.resolve_dev(d_in, w, h, d_out)
+            return self.d2h(d_out, a.shape, np.float32)
+        finally:
+            self.free(d_in)
+            self.free(d_out)
+
     def gen_primary_dev(self, cam, width, height, d_orig, d_dir):
         _check(self.lib.ptgpu_gen_primary_dev(self.handle, C.byref(cam), width, height, d_orig, d_dir))
 
@@ -241,3 +259,18 @@ class Scene:
 
     def gen_shadow_dev(self, light, n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid):
         _check(self.lib.ptgpu_gen_shadow_dev(self.handle, C.byref(light), n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid))
+
+    def render_pass(self, params, cam, lights, accum=None, block_begin=0, block_end=-1, block_stride=1):
+        """One pathTraceBlock pass over the selected blocks, accumulated into (a copy of) accum [h,w,4] on the host."""
+        if accum is None:
+            accum = np.zeros((params.height, params.width, 4), np.float32)
+        accum = np.ascontiguousarray(accum, dtype=np.float32)
+        larr = (Light * len(lights))(*lights)
+        _check(self.lib.ptgpu_render_pass(self.handle, C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), block_begin,
+                                          block_end, block_stride, accum.ctypes.data))
+        return accum
+
+    def render_pass_dev(self, params, cam, lights, d_accum, block_begin=0, block_end=-1, block_stride=1):
+        larr = (Light * len(lights))(*lights)
+        _check(self.lib.ptgpu_render_pass_dev(self.handle, C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), block_begin,
+                                              block_end, block_stride, d_accum))

@@ -1,0 +1,464 @@
+// Persistent-wave path-trace integrator for gfx950.
+//
+// Restates PathTraceRenderer::tracePath (reference src/PathTraceRenderer.cpp:236-551) with the functions it calls:
+// getTextureParameters (:75-181), getLightToSample (:183-210), drawCosineWeightedDirection (:57-73),
+// AreaLight::sample (src/AreaLight.cpp:69-85), sobol::sample (src/sobol.h:39-49), mapToDisk (src/util.cpp:22-47),
+// formBasis (src/RayTracer.cpp:33-55), and the per-sample part of pathTraceBlock (:706-727, :743-779).
+//
+// Execution model (the reference runs one thread per 32x32 block and one sample after another):
+//   * every lane of a wave64 owns ONE path sample at a time and keeps its whole state in registers;
+//   * all lanes that hold a live ray advance the SAME step-wise BVH traverser (pt_traverse.hip.h, one 64-byte record
+//     fetch per step whatever the lane is doing);
+//   * lanes whose ray has finished wait until enough of them have (ballot + popcount), then the wave runs the
+//     "service" section once for all of them: shade / sample the light / start the shadow ray / start the bounce ray /
+//     retire the sample and pull the next one from the wave's sample range (ballot + prefix rank);
+//   * a wave exits when its sample range is exhausted and no lane holds a sample.
+// Which lane or wave computes a sample never affects its value: the sample's Sobol indices and RNG stream are
+// functions of (block, pass_seed, i, k) only, and every arithmetic step is the oracle's, in the oracle's order
+// (no FMA contraction, IEEE divide/sqrt, portable transcendentals) => per-sample radiance is bit-identical to the CPU.
+// Radiance is written per sample; pixels are accumulated afterwards in the reference's order (pt_accumulate kernels).
+#pragma once
+#include "pt_traverse.hip.h"
+#include "../../include/ptgpu.h"
+
+namespace ptd {
+
+struct ShadeScene {
+    const float* pos;  // [num_tris][3][3]
+    const float* nrm;  // [num_tris][3][3]
+    const float* uv;   // [num_tris][3][2]
+    const ptgpu_material* materials;
+    const DevTexture* textures;
+};
+
+// work description of one integrator launch: blocks b = block_begin + (j0 + jj) * block_stride, jj in [0, num_blocks)
+struct PassDesc {
+    int32_t block_begin, block_stride, j0, num_blocks;
+    int32_t blocks_x;          // blocks per image row (reference :816-818)
+    int32_t samples_per_block; // padded: 1024 * num_aa_rays
+    int32_t num_lights;
+    float inv_prob;            // 1 / m_terminationProbability (:468)
+};
+
+__device__ __forceinline__ F4 texel(const DevTexture& t, int x, int y) {
+    x = x < 0 ? 0 : (x > t.width - 1 ? t.width - 1 : x);
+    y = y < 0 ? 0 : (y > t.height - 1 ? t.height - 1 : y);
+    const uint32_t p = *reinterpret_cast<const uint32_t*>(t.rgba + ((size_t)y * t.width + x) * 4);
+    F4 r;
+    r.x = (float)(p & 0xffu) / 255.0f; r.y = (float)((p >> 8) & 0xffu) / 255.0f;
+    r.z = (float)((p >> 16) & 0xffu) / 255.0f; r.w = (float)(p >> 24) / 255.0f;
+    return r;
+}
+__device__ __forceinline__ void texel_coords(F2 uv, const DevTexture& t, int& x, int& y) {
+    x = (int)((uv.x - floorf(uv.x)) * (float)t.width);
+    y = (int)((uv.y - floorf(uv.y)) * (float)t.height);
+}
+
+// src/util.cpp:22-47
+__device__ __forceinline__ void map_to_disk(float a, float b, float& x, float& y) {
+    const float PI = 3.14159265358979323846f;
+    float phi, r;
+    if (a > -b) {
+        if (a > b) { r = a; phi = (PI / 4.0f) * (b / a); }
+        else { r = b; phi = (PI / 4.0f) * (2 - (a / b)); }
+    } else {
+        if (a < b) { r = -a; phi = (PI / 4.0f) * (4.0f + (b / a)); }
+        else {
+            r = -b;
+            if (b != 0) phi = (PI / 4.0f) * (6.0f - (a / b));
+            else phi = 0;
+        }
+    }
+    float s, c;
+    ptm_sincos(phi, s, c);
+    x = r * c;
+    y = r * s;
+}
+
+// src/RayTracer.cpp:33-55, applied to a vector: returns formBasis(n) * v
+__device__ __forceinline__ F3 basis_times(F3 n, F3 v) {
+    float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+    int k = 0;
+    float am = ax;
+    if (ay < am) { k = 1; am = ay; }
+    if (az < am) { k = 2; }
+    F3 q = n;
+    if (k == 0) q.x = 1.0f; else if (k == 1) q.y = 1.0f; else q.z = 1.0f;
+    F3 t = normalize(cross(q, n));
+    F3 b = normalize(cross(n, t));
+    return f3(t.x * v.x + b.x * v.y + n.x * v.z, t.y * v.x + b.y * v.y + n.y * v.z, t.z * v.x + b.z * v.y + n.z * v.z);
+}
+
+__device__ __forceinline__ int sobol_bounce_dim(int bounce) { return bounce > 254 ? 254 : bounce; }
+
+// 32-bit index form of sobol::sample (every index this build forms is a non-negative int)
+__device__ __forceinline__ float sobol32(uint32_t index, unsigned dimension) {
+    unsigned result = 0u;
+    const uint32_t* row = g_sobol_matrices + dimension * 52u;
+    for (unsigned i = 0; index; index >>= 1, ++i) result ^= row[i] & (0u - (index & 1u));
+    return (float)result * (1.f / 4294967296.f);
+}
+// two consecutive dimensions of one index (the reference always draws them in pairs)
+__device__ __forceinline__ void sobol32x2(uint32_t index, unsigned dimension, float& a, float& b) {
+    unsigned ra = 0u, rb = 0u;
+    const uint32_t* row = g_sobol_matrices + dimension * 52u;
+    for (unsigned i = 0; index; index >>= 1, ++i) {
+        uint32_t m = 0u - (index & 1u);
+        ra ^= row[i] & m;
+        rb ^= row[i + 52] & m;
+    }
+    a = (float)ra * (1.f / 4294967296.f);
+    b = (float)rb * (1.f / 4294967296.f);
+}
+
+__device__ __forceinline__ F3 light_col(const ptgpu_light& l, int c) { return f3(l.xform[c * 4], l.xform[c * 4 + 1], l.xform[c * 4 + 2]); }
+
+// src/PathTraceRenderer.cpp:183-210
+__device__ __forceinline__ int get_light_to_sample(F3 pos, const ptgpu_light* lights, int n, Rng& R) {
+    if (n <= 1) return 0;
+    float sum = 0.0f;
+    for (int i = 0; i < n; i++) sum += lights[i].power / length(pos - light_col(lights[i], 3));
+    float r = R.getF32(0.0f, 1.0f);
+    float value = 0.0f;
+    for (int i = 0; i < n; i++) {
+        value += (lights[i].power / length(pos - light_col(lights[i], 3))) / sum;
+        if (r <= value) return i;
+    }
+    return n - 1;
+}
+
+// src/PathTraceRenderer.cpp:75-181
+__device__ __forceinline__ void get_texture_parameters(const ShadeScene& S, const ptgpu_params& prm, int tri, int mat_id, float hu, float hv,
+                                                       F3& diffuse, F3& n, F3& specular) {
+    const ptgpu_material& mat = S.materials[mat_id];
+    const float* tc = S.uv + (size_t)tri * 6;
+    F2 uv0 = ld2(tc), uv1 = ld2(tc + 2), uv2 = ld2(tc + 4);
+    F2 uv = (1 - hu - hv) * uv0 + hu * uv1 + hv * uv2;
+
+    diffuse = f3(mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]);
+    if (mat.tex_diffuse >= 0) {
+        DevTexture tex = S.textures[mat.tex_diffuse];
+        if (prm.bilinear) {
+            float fx = uv.x - floorf(uv.x);
+            float fy = uv.y - floorf(uv.y);
+            float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+            float w1 = fx1 * fy1, w2 = fx * fy1, w3 = fx1 * fy, w4 = fx * fy;
+            int x1 = (int)sel_min(sel_max(fx * (float)tex.width - 0.5f, 0.0f), (float)tex.width - 2.0f);
+            int y1 = (int)sel_min(sel_max(fy * (float)tex.height - 0.5f, 0.0f), (float)tex.height - 2.0f);
+            int x2 = x1 + 1, y2 = y1 + 1;
+            F4 d1 = texel(tex, x1, y1), d2 = texel(tex, x2, y1), d3 = texel(tex, x1, y2), d4 = texel(tex, x2, y2);
+            diffuse = f3(d1.x * w1 + d2.x * w2 + d3.x * w3 + d4.x * w4,
+                         d1.y * w1 + d2.y * w2 + d3.y * w3 + d4.y * w4,
+                         d1.z * w1 + d2.z * w2 + d3.z * w3 + d4.z * w4);
+        } else {
+            int x, y;
+            texel_coords(uv, tex, x, y);
+            F4 d = texel(tex, x, y);
+            diffuse = f3(d.x, d.y, d.z);
+        }
+        diffuse = f3(ptm_pow(diffuse.x, 2.2f), ptm_pow(diffuse.y, 2.2f), ptm_pow(diffuse.z, 2.2f));
+    }
+    const float* nn = S.nrm + (size_t)tri * 9;
+    n = normalize((1 - hu - hv) * ld3(nn) + hu * ld3(nn + 3) + hv * ld3(nn + 6));
+
+    if (mat.tex_normal >= 0 && prm.normal_mapped) {
+        DevTexture tex = S.textures[mat.tex_normal];
+        int x, y;
+        texel_coords(uv, tex, x, y);
+        F4 tv = texel(tex, x, y);
+        F3 texture_normal = f3(2.0f * tv.x - 1.0f, 2.0f * tv.y - 1.0f, 2.0f * tv.z - 1.0f);
+        const float* pp = S.pos + (size_t)tri * 9;
+        F3 v0 = ld3(pp), v1 = ld3(pp + 3), v2 = ld3(pp + 6);
+        F3 deltaPos1 = v1 - v0, deltaPos2 = v2 - v0;
+        F2 deltaUV1 = uv1 - uv0, deltaUV2 = uv2 - uv0;
+        float r = 1.0f / (deltaUV1.x * deltaUV2.y - deltaUV1.y * deltaUV2.x);
+        F3 tangent = normalize((deltaPos1 * deltaUV2.y - deltaPos2 * deltaUV1.y) * r);
+        F3 bitangent = normalize((deltaPos2 * deltaUV1.x - deltaPos1 * deltaUV2.x) * r);
+        F3 tn = texture_normal;
+        n = normalize(f3(tangent.x * tn.x + bitangent.x * tn.y + n.x * tn.z, tangent.y * tn.x + bitangent.y * tn.y + n.y * tn.z,
+                         tangent.z * tn.x + bitangent.z * tn.y + n.z * tn.z));
+    }
+    specular = f3(mat.specular[0], mat.specular[1], mat.specular[2]);
+    if (mat.tex_specular >= 0) {
+        DevTexture tex = S.textures[mat.tex_specular];
+        int x, y;
+        texel_coords(uv, tex, x, y);
+        F4 d = texel(tex, x, y);
+        specular = f3(d.x, d.y, d.z);
+    }
+}
+
+// src/PathTraceRenderer.cpp:52-55
+__device__ __forceinline__ float gauss(float x, float y) {
+    const float PI = 3.14159265358979323846f;
+    float sigma = 1.0f;
+    return 1.0f / (sqrtf(2.0f * PI) * sigma) * ptm_exp(-1.0f * (x * x + y * y) / (2.0f * sigma * sigma));
+}
+
+// Sobol sequence base of a block (reference :689-694); see oracle block_sobol_base for the deviation note
+__device__ __forceinline__ int block_sobol_base(int idx, uint32_t pass_seed) {
+    Rng Rb;
+    Rb.seed((uint32_t)idx, pass_seed, 0xB10Cu, 0u);
+    int mul = Rb.getS32(1, 9);
+    int add = Rb.getS32(1, 12345);
+    return idx * mul + add;
+}
+
+// per-lane path state between two service rounds
+enum : int { ST_IDLE = 0, ST_EXT = 1, ST_SH = 2 };
+
+struct PathState {
+    F3 O, N, V, diffuse, specular, throughput, Ei, emission, L;
+    float gloss, normalization, pdf, terminate, aux;  // aux: 4th output word (local pixel bits or Gaussian weight)
+    int li, bounce, base, mode, stage;
+    long long sid;
+    Rng R;
+};
+
+// One integrator launch.  rad[sid] = (Ei.rgb, aux) for every valid padded sample id of the launch's blocks.
+// spill: samples of Sobol-block mode whose pixel falls outside their own block (sobol() == 1.0f exactly, p = 2^-24).
+template <bool COUNT, int NLDS, bool OVF, int BLOCK>
+__device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene& SS, const ptgpu_params& prm, const ptgpu_camera& cam,
+                                          const ptgpu_light* __restrict__ lights, const PassDesc& pd, float4* __restrict__ rad,
+                                          unsigned long long* counters, uint2* lds_lane, int service_threshold) {
+    const int lane = threadIdx.x & 63;
+    Trav<true, COUNT, NLDS, OVF> tr;
+    tr.reset_counts();
+    tr.alive = false;
+    PathState ps;
+    ps.stage = ST_IDLE;
+    ps.sid = -1;
+    uint32_t n_rays = 0;
+
+    const long long total = (long long)pd.num_blocks * pd.samples_per_block;
+    const long long total_waves = (long long)gridDim.x * (BLOCK / 64);
+    const long long wave_id = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    long long next = 0, end = 0, round = -1;
+    bool exhausted = false;
+    const int bounces = prm.bounces < 0 ? -prm.bounces : prm.bounces;
+    const float div_x = 1.0f / (float)prm.width, div_y = 1.0f / (float)prm.height;
+    const float PI = 3.14159265358979323846f;
+
+    for (;;) {
+        const unsigned long long running = __ballot(tr.alive);
+        const unsigned long long waiting = __ballot(!tr.alive && (ps.stage != ST_IDLE || !exhausted));
+        const int n_run = __popcll(running), n_wait = __popcll(waiting);
+        if (n_run == 0 && n_wait == 0) break;  // exhausted and every lane idle
+        if (n_wait > 0 && (n_run == 0 || n_wait >= service_threshold || n_wait >= n_run)) {
+            // ------------------------------------------------------------------ service section
+            bool do_hit = false, do_bounce = false, do_finish = false;
+            int hit_tri = -1, hit_mat = 0;
+            float hit_u = 0.0f, hit_v = 0.0f;
+            if (!tr.alive && ps.stage != ST_IDLE) {
+                int next_ctl = 0;  // 0 none, 1 fixed-bounce check, 2 roulette entry, 3 roulette check
+                if (ps.stage == ST_SH) {
+                    if (tr.pmin < 0) {
+                        // unoccluded: reference :346-376 / :416-450 / :500-534
+                        const ptgpu_light& Lt = lights[ps.li];
+                        F3 D = normalize(ps.L);
+                        F3 Nl = -light_col(Lt, 2);
+                        if (dot(ps.N, ps.V) > 0.0f) ps.N = ps.N * -1.0f;
+                        float cos_theta = sel_max(0.0f, dot(ps.N, D));
+                        float cos_theta_l = sel_max(0.0f, dot(Nl, -D));
+                        float d = length(ps.L);
+                        float inv_d = sel_min(1.0f / (d * d), 100000.0f);
+                        float inv_pdf = sel_min(1.0f / ps.pdf, 100000.0f);
+                        F3 H = normalize(D - ps.V);
+                        F3 color = ps.diffuse;
+                        color = color + ps.specular * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
+                        const float invPi = 0.31830988618379f;
+                        F3 c;
+                        if (ps.mode == 0) c = color * invPi * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
+                        else if (ps.mode == 1) c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
+                        else c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf * pd.inv_prob;
+                        ps.Ei = ps.Ei + c;
+                    }
+                    next_ctl = 1;
+                    if (ps.mode == 1) ps.bounce += 1;
+                    if (ps.mode == 2) { ps.terminate = ps.R.getF32(0.0f, 1.0f); ps.bounce += 1; next_ctl = 3; }
+                } else {  // ST_EXT
+                    if (tr.pmin >= 0) {
+                        do_hit = true;
+                        float4 rec = TS.tris[(size_t)tr.pmin * 4 + 3];
+                        hit_tri = __float_as_int(rec.x);
+                        hit_mat = __float_as_int(rec.w);
+                        hit_u = tr.umin; hit_v = tr.vmin;
+                    } else if (ps.mode == 1) next_ctl = 2;  // miss inside the fixed-bounce loop: `break`, then the roulette section
+                    else do_finish = true;                  // primary miss (Ei = 0) or miss inside the roulette loop
+                }
+                if (next_ctl == 1) {
+                    if (ps.bounce < bounces) { ps.mode = 1; do_bounce = true; }
+                    else next_ctl = 2;
+                }
+                if (next_ctl == 2) {
+                    if (prm.bounces < 0) { ps.terminate = ps.R.getF32(0.0f, 1.0f); next_ctl = 3; }
+                    else do_finish = true;
+                }
+                if (next_ctl == 3) {
+                    if (ps.terminate > prm.termination_prob) { ps.mode = 2; do_bounce = true; }
+                    else do_finish = true;
+                }
+            }
+            if (do_hit) {
+                // reference :300-344 (first hit) and :403-414 / :486-498 (bounce hits)
+                F3 point = tr.o + tr.tmin * tr.d;
+                if (ps.mode == 0) {
+                    ps.gloss = SS.materials[hit_mat].glossiness;
+                    ps.normalization = (ps.gloss + 2.0f) / (4.0f * PI * (2.0f - ptm_pow(2.0f, -ps.gloss / 2.0f)));
+                    ps.bounce = 0;
+                    ps.throughput = f3(1.0f, 1.0f, 1.0f);
+                    ps.V = normalize(tr.d);
+                }
+                ps.O = point;
+                get_texture_parameters(SS, prm, hit_tri, hit_mat, hit_u, hit_v, ps.diffuse, ps.N, ps.specular);
+                ps.li = get_light_to_sample(ps.O, lights, pd.num_lights, ps.R);
+                const ptgpu_light& Lt = lights[ps.li];
+                // AreaLight::sample, src/AreaLight.cpp:69-85
+                int dim = 4 + 4 * sobol_bounce_dim(ps.bounce);
+                int r = ps.R.getS32(1, 10000);
+                float sa, sb;
+                sobol32x2((uint32_t)(ps.base + r), (unsigned)dim, sa, sb);
+                float lx = (2.0f * sa - 1.0f) * Lt.size[0];
+                float ly = (2.0f * sb - 1.0f) * Lt.size[1];
+                F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * lx + light_col(Lt, 1) * ly;
+                ps.pdf = 1.0f / (4.0f * Lt.size[0] * Lt.size[1]);
+                ps.L = Pl - ps.O;
+                if (ps.mode == 0) ps.emission = f3(Lt.E[0], Lt.E[1], Lt.E[2]) * prm.intensity;  // once per path (:341)
+                tr.begin(TS, ps.O + 0.0001f * ps.N, ps.L, true, lds_lane);
+                n_rays += 1;
+                ps.stage = ST_SH;
+            }
+            if (do_bounce) {
+                // reference :391-401 / :473-484; drawCosineWeightedDirection :57-73 (RNG peeked, not advanced)
+                int dim = 2 + 4 * sobol_bounce_dim(ps.bounce);
+                int rnd = ps.R.peekS32(1, 1234);
+                float sa, sb;
+                sobol32x2((uint32_t)(ps.base + rnd), (unsigned)dim, sa, sb);
+                float a = 2.0f * sa - 1.0f, b = 2.0f * sb - 1.0f;
+                float x, y;
+                map_to_disk(a, b, x, y);
+                float z = sqrtf(1 - x * x - y * y);
+                ps.V = normalize(basis_times(ps.N, f3(x, y, z)));
+                ps.throughput = ps.throughput * ps.diffuse;
+                tr.begin(TS, ps.O + 0.0001f * ps.N, cam.far_ * ps.V, false, lds_lane);
+                n_rays += 1;
+                ps.stage = ST_EXT;
+            }
+            if (do_finish) {
+                float4 o;
+                o.x = ps.Ei.x; o.y = ps.Ei.y; o.z = ps.Ei.z; o.w = ps.aux;
+                rad[ps.sid] = o;
+                ps.stage = ST_IDLE;
+                ps.sid = -1;
+            }
+            // ---- pull new samples for idle lanes (ballot + prefix rank over the wave's current chunk)
+            unsigned long long need = __ballot(ps.stage == ST_IDLE);
+            while (need != 0ull && !exhausted) {
+                if (next >= end) {
+                    round += 1;
+                    const long long cbase = (round * total_waves + (wave_id + round * 997) % total_waves) * 64;
+                    if (cbase >= total) { exhausted = true; break; }
+                    next = cbase;
+                    end = next + 64 < total ? next + 64 : total;
+                }
+                const int avail = (int)(end - next);
+                const int rank = __popcll(need & ((1ull << lane) - 1ull));
+                if (ps.stage == ST_IDLE && rank < avail) {
+                    const long long sid = next + rank;
+                    const int jj = (int)(sid / pd.samples_per_block);
+                    const int s = (int)(sid - (long long)jj * pd.samples_per_block);
+                    const int idx = pd.block_begin + (pd.j0 + jj) * pd.block_stride;
+                    const int bx = (idx % pd.blocks_x) * 32, by = (idx / pd.blocks_x) * 32;
+                    const int bw = (bx + 32 < prm.width) ? 32 : prm.width - bx;
+                    const int bh = (by + 32 < prm.height) ? 32 : prm.height - by;
+                    const int base = block_sobol_base(idx, prm.pass_seed);
+                    bool valid;
+                    float px, py;
+                    int sbase;
+                    if (prm.sobol_block) {  // reference :706-727
+                        const int i = s;
+                        valid = i < bw * bh * prm.num_aa_rays;
+                        float sa, sb;
+                        sobol32x2((uint32_t)(base + i), 0u, sa, sb);
+                        px = (float)bx + (float)bw * sa;
+                        py = (float)by + (float)bh * sb;
+                        sbase = base + i;
+                        ps.R.seed((uint32_t)idx, prm.pass_seed, (uint32_t)i, 0u);
+                        int pixel_x = (int)floorf(px); if (pixel_x > prm.width - 1) pixel_x = prm.width - 1;
+                        int pixel_y = (int)floorf(py); if (pixel_y > prm.height - 1) pixel_y = prm.height - 1;
+                        ps.aux = __int_as_float(pixel_y * prm.width + pixel_x);  // global pixel index; accumulate checks the block
+                    } else {  // reference :743-779
+                        const int i = s / prm.num_aa_rays, k = s - i * prm.num_aa_rays;
+                        valid = i < bw * bh;
+                        const int pixel_x = bx + (i % bw), pixel_y = by + (i / bw);
+                        float sa, sb;
+                        sobol32x2((uint32_t)(base + i + k), 0u, sa, sb);
+                        float a = prm.filter_width * (sa - 0.5f) + 0.5f;
+                        float b = prm.filter_width * (sb - 0.5f) + 0.5f;
+                        px = (float)pixel_x + a;
+                        py = (float)pixel_y + b;
+                        if (px < 0.0f) px *= -1.0f;
+                        if (py < 0.0f) py *= -1.0f;
+                        if (px > (float)prm.width) px -= a;
+                        if (py > (float)prm.height) py -= b;
+                        sbase = base + i;
+                        ps.R.seed((uint32_t)idx, prm.pass_seed, (uint32_t)i, (uint32_t)k);
+                        const float fs = 2.0f / prm.filter_width;
+                        ps.aux = gauss(fs * (a - 0.5f), fs * (b - 0.5f));
+                    }
+                    if (valid) {
+                        float x = px * div_x * 2.0f - 1.0f;
+                        float y = py * div_y * -2.0f + 1.0f;
+                        // camera ray, reference :244-292
+                        F4 Roh = mul44(cam.invP, x, y, 0.0f, 1.0f);
+                        float iw0 = 1.0f / Roh.w;
+                        F3 Ro = f3(Roh.x * iw0, Roh.y * iw0, Roh.z * iw0);
+                        F4 Rdh = mul44(cam.invP, x, y, 1.0f, 1.0f);
+                        float iw1 = 1.0f / Rdh.w;
+                        F3 Rd = f3(Rdh.x * iw1, Rdh.y * iw1, Rdh.z * iw1) - Ro;
+                        if (prm.depth_of_field) {
+                            F3 Rn = normalize(Rd);
+                            F3 Pn = f3(cam.forward[0], cam.forward[1], cam.forward[2]);
+                            float Pd = prm.focal_distance / sel_max(0.01f, dot(Rn, Pn));
+                            F3 Rf = Ro + Pd * Rn;
+                            float xr, yr;
+                            float a = ps.R.getF32(-1.0f, 1.0f);
+                            float b = ps.R.getF32(-1.0f, 1.0f);
+                            map_to_disk(a, b, xr, yr);
+                            F3 up = f3(cam.orient_col0[0], cam.orient_col0[1], cam.orient_col0[2]);
+                            F3 right = f3(cam.orient_col1[0], cam.orient_col1[1], cam.orient_col1[2]);
+                            Ro = Ro + prm.aperture * (yr * up + xr * right);
+                            Rd = cam.far_ * normalize(Rf - Ro);
+                        }
+                        ps.sid = sid;
+                        ps.base = sbase;
+                        ps.mode = 0;
+                        ps.bounce = 0;
+                        ps.Ei = f3(0.0f, 0.0f, 0.0f);
+                        tr.begin(TS, Ro, Rd, false, lds_lane);
+                        n_rays += 1;
+                        ps.stage = ST_EXT;
+                    } else {
+                        ps.stage = ST_EXT;  // placeholder so that this lane is not handed a second id in this while-loop pass
+                        ps.sid = -2;
+                    }
+                }
+                const int n_need = __popcll(need);
+                next += n_need < avail ? n_need : avail;
+                need = __ballot(ps.stage == ST_IDLE);
+            }
+            if (ps.sid == -2) { ps.stage = ST_IDLE; ps.sid = -1; }  // padded sample id: nothing to trace
+        }
+        if (tr.alive) tr.step(TS);
+    }
+    // 1 ray = 1 raycast() call (reference src/RayTracer.cpp:192)
+    unsigned long long wr = n_rays;
+    for (int off = 32; off > 0; off >>= 1) wr += __shfl_down(wr, off);
+    if (lane == 0 && wr) atomicAdd(&counters[0], wr);
+    if (COUNT) {
+        atomicAdd(&counters[1], (unsigned long long)tr.n_nodes);
+        atomicAdd(&counters[2], (unsigned long long)tr.n_tris);
+    }
+}
+
+}  // namespace ptd

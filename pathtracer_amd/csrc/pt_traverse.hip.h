@@ -42,6 +42,7 @@ struct TravScene {
     int32_t list_size;    // 0 => empty scene, every ray misses
     const float* uv;      // [num_tris][3][2], for the alpha cutout only
     const DevTexture* textures;
+    int32_t alpha_on;     // RayTracer::useAlpha && the scene has an alpha map (only read by ALPHA instantiations)
 };
 
 struct HitRec {
@@ -176,7 +177,7 @@ __device__ __forceinline__ HitRec traverse(const TravScene& S, F3 o, F3 d, uint2
                 bool keep = true;
                 if (ALPHA) {
                     int atex = __float_as_int(r3.z);
-                    if (atex >= 0) {  // RayTracer.cpp:204-225: green channel of the alpha map < 0.5 => cut out
+                    if (S.alpha_on && atex >= 0) {  // RayTracer.cpp:204-225: green channel of the alpha map < 0.5 => cut out
                         const float* tc = S.uv + (size_t)__float_as_int(r3.x) * 6;
                         F2 uv = (1 - u - v) * ld2(tc) + u * ld2(tc + 2) + v * ld2(tc + 4);
                         DevTexture tx = S.textures[atex];
@@ -308,7 +309,7 @@ struct Trav {
                 bool keep = true;
                 if (ALPHA) {
                     int atex = __float_as_int(m.z);
-                    if (atex >= 0) {
+                    if (S.alpha_on && atex >= 0) {
                         const float* tc = S.uv + (size_t)__float_as_int(m.x) * 6;
                         F2 uv = (1 - u - v) * ld2(tc) + u * ld2(tc + 2) + v * ld2(tc + 4);
                         DevTexture tx = S.textures[atex];

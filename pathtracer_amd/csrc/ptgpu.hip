@@ -11,6 +11,7 @@
 
 #include "../../include/ptgpu.h"
 #include "pt_traverse.hip.h"
+#include "pt_integrator.hip.h"
 
 namespace ptd {
 __device__ const uint32_t g_sobol_matrices[1024 * 52] = {
@@ -42,9 +43,17 @@ struct ptgpu_context {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool count = false;
-    unsigned long long* d_counters = nullptr;  // rays, node visits, triangle tests
+    unsigned long long* d_counters = nullptr;  // rays, node visits, triangle tests, [3] spill entries, [4] spill overflow
     int num_cu = 256;
+    // render workspace (grow-only): per-sample radiance of one batch of blocks, light table, spill list
+    float4* d_rad = nullptr;
+    size_t rad_capacity = 0;  // samples
+    ptgpu_light* d_lights = nullptr;
+    std::vector<ptgpu_light> h_lights;  // what d_lights holds
+    float4* d_spill = nullptr;
 };
+constexpr int CTR_WORDS = 8;
+constexpr int SPILL_CAPACITY = 1 << 16;
 
 struct ptgpu_scene {
     ptgpu_context* ctx = nullptr;
@@ -79,8 +88,8 @@ extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIP_TRY(hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->d_counters, CTR_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_counters, 0, CTR_WORDS * sizeof(unsigned long long)));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out_ctx = c;
     return PTGPU_OK;
@@ -91,6 +100,9 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->d_counters) hipFree(c->d_counters);
+    if (c->d_rad) hipFree(c->d_rad);
+    if (c->d_lights) hipFree(c->d_lights);
+    if (c->d_spill) hipFree(c->d_spill);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return PTGPU_OK;
@@ -160,7 +172,7 @@ extern "C" int ptgpu_get_counters(ptgpu_context* c, ptgpu_counters* out) {
 extern "C" int ptgpu_reset_counters(ptgpu_context* c) {
     if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));  // spill words are cleared per pass
     return PTGPU_OK;
 }
 
@@ -486,6 +498,8 @@ static int launch_rc_impl(ptgpu_scene* s, int impl, const float* o, const float*
     ptgpu_context* c = s->ctx;
     hipStream_t st = c->stream;
     dim3 block(RC_BLOCK);
+    ptd::TravScene trav = s->trav;
+    trav.alpha_on = ALPHA ? 1 : 0;
     if (impl == 2) {
         long long want = (n + RC_CHUNK - 1) / RC_CHUNK;  // no more waves than chunks
         long long blocks = (want + (RC_BLOCK / 64) - 1) / (RC_BLOCK / 64);
@@ -498,14 +512,14 @@ static int launch_rc_impl(ptgpu_scene* s, int impl, const float* o, const float*
         }
         long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_RAYCAST_OVERSUB", 2);
         if (blocks > resident) blocks = resident;
-        hipLaunchKernelGGL((k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>), dim3((unsigned)blocks), block, 0, st, s->trav, o, d, n, id, t,
+        hipLaunchKernelGGL((k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>), dim3((unsigned)blocks), block, 0, st, trav, o, d, n, id, t,
                            u, v, c->d_counters, env_int("PTGPU_RAYCAST_REFILL", 32));
     } else {
         dim3 grid((unsigned)((n + RC_BLOCK - 1) / RC_BLOCK));
         if (impl == 1)
-            hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, NLDS, OVF>), grid, block, 0, st, s->trav, o, d, n, id, t, u, v, c->d_counters);
+            hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, NLDS, OVF>), grid, block, 0, st, trav, o, d, n, id, t, u, v, c->d_counters);
         else if constexpr (NLDS == RC_NLDS)
-            hipLaunchKernelGGL((k_raycast<ANYHIT, ALPHA, COUNT, OVF>), grid, block, 0, st, s->trav, o, d, n, id, t, u, v, c->d_counters);
+            hipLaunchKernelGGL((k_raycast<ANYHIT, ALPHA, COUNT, OVF>), grid, block, 0, st, trav, o, d, n, id, t, u, v, c->d_counters);
         else
             return fail(PTGPU_E_UNSUPPORTED, "while-while kernel is only built with %d LDS stack entries", RC_NLDS);
     }
@@ -657,6 +671,268 @@ extern "C" int ptgpu_gen_shadow_dev(ptgpu_scene* s, const ptgpu_light* light, in
     HIP_TRY(hipSetDevice(s->ctx->device));
     hipLaunchKernelGGL(k_gen_shadow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->ctx->stream, s->d_nrm, s->num_tris, *light, (long long)n,
                        d_orig, d_dir, d_id, d_t, d_u, d_v, d_sh_orig, d_sh_dir, d_sh_valid);
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PathTraceRenderer: one pass of pathTraceBlock over a set of 32x32 blocks (reference src/PathTraceRenderer.cpp:663-790)
+//   k_integrate        per-sample radiance (tracePath) -> rad[padded sample id]
+//   k_accum_sobol      m_sobolBlock == true:  pixel += (color, 1) / NumAaRays in sample order i (:727-732)
+//   k_accum_gauss      m_sobolBlock == false: Gaussian-weighted per-pixel mean over k, saturate, pixel += (:743-787)
+//   k_apply_spill      Sobol-block samples whose pixel lies outside their own block (sobol() rounds to 1.0f)
+//   k_resolve          updatePicture (:855-871)
+// ------------------------------------------------------------------------------------------------
+constexpr int PT_BLOCK = 256;
+constexpr int PT_NLDS = 24;
+
+template <bool COUNT, bool OVF>
+__global__ __launch_bounds__(PT_BLOCK) void k_integrate(ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
+                                                        const ptgpu_light* __restrict__ lights, ptd::PassDesc pd, float4* __restrict__ rad,
+                                                        unsigned long long* counters, int service_threshold) {
+    __shared__ uint2 lds_stack[PT_BLOCK / 64][PT_NLDS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ptd::integrate<COUNT, PT_NLDS, OVF, PT_BLOCK>(TS, SS, prm, cam, lights, pd, rad, counters, &lds_stack[wave][0][lane], service_threshold);
+}
+
+__device__ __forceinline__ void block_rect(const ptgpu_params& prm, const ptd::PassDesc& pd, int jj, int& bx, int& by, int& bw, int& bh) {
+    const int idx = pd.block_begin + (pd.j0 + jj) * pd.block_stride;
+    bx = (idx % pd.blocks_x) * 32; by = (idx / pd.blocks_x) * 32;
+    bw = (bx + 32 < prm.width) ? 32 : prm.width - bx;
+    bh = (by + 32 < prm.height) ? 32 : prm.height - by;
+}
+
+__global__ __launch_bounds__(256) void k_accum_sobol(ptgpu_params prm, ptd::PassDesc pd, const float4* __restrict__ rad, float* __restrict__ accum,
+                                                     float4* __restrict__ spill, unsigned long long* counters) {
+    __shared__ float4 acc[1024];
+    __shared__ int owner[1024];
+    const int jj = blockIdx.x, tid = threadIdx.x;
+    int bx, by, bw, bh;
+    block_rect(prm, pd, jj, bx, by, bw, bh);
+    const int n = bw * bh * prm.num_aa_rays;
+    const float scale = 1.0f / (float)prm.num_aa_rays;
+    float4* img = reinterpret_cast<float4*>(accum);
+    for (int p = tid; p < 1024; p += 256) {
+        const int lx = p & 31, ly = p >> 5;
+        acc[p] = (lx < bw && ly < bh) ? img[(size_t)(by + ly) * prm.width + bx + lx] : make_float4(0, 0, 0, 0);
+        owner[p] = 0x7fffffff;
+    }
+    __syncthreads();
+    const float4* src = rad + (size_t)jj * pd.samples_per_block;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + tid;
+        bool pending = false;
+        float4 r = make_float4(0, 0, 0, 0);
+        int lp = 0;
+        if (i < n) {
+            r = src[i];
+            const int gp = __float_as_int(r.w);
+            const int gx = gp % prm.width, gy = gp / prm.width;
+            if (gx >= bx && gx < bx + bw && gy >= by && gy < by + bh) {
+                lp = (gy - by) * 32 + (gx - bx);
+                pending = true;
+            } else {
+                const unsigned long long slot = atomicAdd(&counters[3], 1ull);
+                if (slot < (unsigned long long)SPILL_CAPACITY) spill[slot] = make_float4(r.x * scale, r.y * scale, r.z * scale, r.w);
+                else atomicAdd(&counters[4], 1ull);
+            }
+        }
+        // add in sample order: among the pending samples of one pixel the lowest thread (= lowest i) goes first
+        while (__syncthreads_or(pending ? 1 : 0)) {
+            if (pending) atomicMin(&owner[lp], tid);
+            __syncthreads();
+            if (pending && owner[lp] == tid) {
+                float4 a = acc[lp];
+                a.x += r.x * scale; a.y += r.y * scale; a.z += r.z * scale; a.w += 1.0f * scale;
+                acc[lp] = a;
+                pending = false;
+                owner[lp] = 0x7fffffff;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < 1024; p += 256) {
+        const int lx = p & 31, ly = p >> 5;
+        if (lx < bw && ly < bh) img[(size_t)(by + ly) * prm.width + bx + lx] = acc[p];
+    }
+}
+
+__global__ void k_apply_spill(ptgpu_params prm, const float4* __restrict__ spill, float* __restrict__ accum, const unsigned long long* counters) {
+    unsigned long long n = counters[3];
+    if (n > (unsigned long long)SPILL_CAPACITY) n = SPILL_CAPACITY;
+    const float scale = 1.0f / (float)prm.num_aa_rays;
+    for (unsigned long long e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * blockDim.x) {
+        const float4 s = spill[e];
+        const int gp = __float_as_int(s.w);
+        if (gp < 0 || gp >= prm.width * prm.height) continue;
+        float* px = accum + (size_t)gp * 4;
+        atomicAdd(px, s.x); atomicAdd(px + 1, s.y); atomicAdd(px + 2, s.z); atomicAdd(px + 3, 1.0f * scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_accum_gauss(ptgpu_params prm, ptd::PassDesc pd, const float4* __restrict__ rad, float* __restrict__ accum) {
+    const int jj = blockIdx.x;
+    int bx, by, bw, bh;
+    block_rect(prm, pd, jj, bx, by, bw, bh);
+    float4* img = reinterpret_cast<float4*>(accum);
+    for (int i = threadIdx.x; i < bw * bh; i += 256) {
+        const int pixel_x = bx + (i % bw), pixel_y = by + (i / bw);
+        const float4* src = rad + (size_t)jj * pd.samples_per_block + (size_t)i * prm.num_aa_rays;
+        float cx = 0.0f, cy = 0.0f, cz = 0.0f, cw = 0.0f;
+        for (int k = 0; k < prm.num_aa_rays; ++k) {
+            const float4 r = src[k];
+            const float g = r.w;
+            cx += g * r.x; cy += g * r.y; cz += g * r.z; cw += g * 1.0f;
+        }
+        cx = cx / cw; cy = cy / cw; cz = cz / cw; cw = cw / cw;
+        // saturate(), reference :36-49
+        const float Pr = 0.299f, Pg = 0.587f, Pb = 0.114f;
+        const float amount = prm.attenuation;
+        const float P = sqrtf(cx * cx * Pr + cy * cy * Pg + cz * cz * Pb);
+        cx = P + (cx - P) * amount; cy = P + (cy - P) * amount; cz = P + (cz - P) * amount;
+        cx = cx < 0.0f ? 0.0f : (cx > 1.0f ? 1.0f : cx);
+        cy = cy < 0.0f ? 0.0f : (cy > 1.0f ? 1.0f : cy);
+        cz = cz < 0.0f ? 0.0f : (cz > 1.0f ? 1.0f : cz);
+        cw = cw < 0.0f ? 0.0f : (cw > 1.0f ? 1.0f : cw);
+        float4 a = img[(size_t)pixel_y * prm.width + pixel_x];
+        a.x += cx; a.y += cy; a.z += cz; a.w += cw;
+        img[(size_t)pixel_y * prm.width + pixel_x] = a;
+    }
+}
+
+__global__ void k_resolve(const float4* __restrict__ accum, long long n, float4* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 D = accum[i];
+    if (D.w != 0.0f) {
+        float r = 1.0f / D.w;
+        D = make_float4(D.x * r, D.y * r, D.z * r, D.w * r);
+    }
+    const float g = 1.0f / 2.2f;
+    out[i] = make_float4(ptd::ptm_pow(D.x, g), ptd::ptm_pow(D.y, g), ptd::ptm_pow(D.z, g), D.w);
+}
+
+static int check_params(const ptgpu_params* p) {
+    if (p->width <= 0 || p->height <= 0) return fail(PTGPU_E_INVALID, "image size %dx%d", p->width, p->height);
+    if ((long long)p->width * p->height > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "image too large");
+    if (p->num_aa_rays < 1 || p->num_aa_rays > 65536) return fail(PTGPU_E_INVALID, "num_aa_rays %d out of range [1,65536]", p->num_aa_rays);
+    if (p->whitted) return fail(PTGPU_E_UNSUPPORTED, "Whitted mode (traceWhitted) is not on the device path yet");
+    if (p->bounces < 0 && !(p->termination_prob > 0.0f)) return fail(PTGPU_E_INVALID, "termination_prob must be > 0 with Russian roulette");
+    if (!p->sobol_block && !(p->filter_width > 0.0f)) return fail(PTGPU_E_INVALID, "filter_width must be > 0");
+    return PTGPU_OK;
+}
+
+template <bool COUNT, bool OVF>
+static void launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const ptd::ShadeScene& ss, const ptgpu_params* prm, const ptgpu_camera* cam,
+                             const ptd::PassDesc& pd) {
+    ptgpu_context* c = s->ctx;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_integrate<COUNT, OVF>, PT_BLOCK, 0) != hipSuccess || v < 1) v = 1;
+        per_cu = v;
+    }
+    const long long total = (long long)pd.num_blocks * pd.samples_per_block;
+    long long blocks = (total + PT_BLOCK - 1) / PT_BLOCK;
+    const long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_PT_OVERSUB", 1);
+    if (blocks > resident) blocks = resident;
+    hipLaunchKernelGGL((k_integrate<COUNT, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
+                       c->d_counters, env_int("PTGPU_PT_SERVICE", 24));
+}
+
+extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, const ptgpu_camera* cam, const ptgpu_light* lights, int32_t num_lights,
+                                     int32_t block_begin, int32_t block_end, int32_t block_stride, float* d_accum) {
+    if (!s || !prm || !cam || !lights || !d_accum) return fail(PTGPU_E_INVALID, "NULL argument");
+    int rc = check_params(prm);
+    if (rc != PTGPU_OK) return rc;
+    if (num_lights < 1 || num_lights > 1024) return fail(PTGPU_E_INVALID, "num_lights %d out of range [1,1024]", num_lights);
+    const int blocks_x = (prm->width + 31) / 32, blocks_y = (prm->height + 31) / 32;
+    const int nblocks = blocks_x * blocks_y;
+    if (block_end < 0 || block_end > nblocks) block_end = nblocks;
+    if (block_begin < 0 || block_stride < 1) return fail(PTGPU_E_INVALID, "block range [%d,%d) stride %d", block_begin, block_end, block_stride);
+    if (block_begin >= block_end) return PTGPU_OK;
+    ptgpu_context* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    // light table: re-uploaded only when it changed (synchronous, rare)
+    if ((int)c->h_lights.size() != num_lights || memcmp(c->h_lights.data(), lights, sizeof(ptgpu_light) * num_lights) != 0) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_lights) { HIP_TRY(hipFree(c->d_lights)); c->d_lights = nullptr; }
+        HIP_TRY(hipMalloc(&c->d_lights, sizeof(ptgpu_light) * num_lights));
+        HIP_TRY(hipMemcpy(c->d_lights, lights, sizeof(ptgpu_light) * num_lights, hipMemcpyHostToDevice));
+        c->h_lights.assign(lights, lights + num_lights);
+    }
+    if (!c->d_spill) HIP_TRY(hipMalloc(&c->d_spill, sizeof(float4) * SPILL_CAPACITY));
+    const int count = (block_end - block_begin + block_stride - 1) / block_stride;  // blocks of this call
+    const long long spb = 1024LL * prm->num_aa_rays;
+    long long batch_samples = (long long)env_int("PTGPU_PT_BATCH_MSAMPLES", 64) << 20;
+    long long batch_blocks = batch_samples / spb;
+    if (batch_blocks < 1) batch_blocks = 1;
+    if (batch_blocks > count) batch_blocks = count;
+    const size_t need = (size_t)(batch_blocks * spb);
+    if (need > c->rad_capacity) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rad) { HIP_TRY(hipFree(c->d_rad)); c->d_rad = nullptr; c->rad_capacity = 0; }
+        HIP_TRY(hipMalloc(&c->d_rad, need * sizeof(float4)));
+        c->rad_capacity = need;
+    }
+    ptd::TravScene trav = s->trav;
+    trav.alpha_on = (prm->use_alpha && s->has_alpha) ? 1 : 0;
+    ptd::ShadeScene ss;
+    ss.pos = s->d_pos; ss.nrm = s->d_nrm; ss.uv = s->d_uv; ss.materials = s->d_materials; ss.textures = s->d_textures;
+    const bool ovf = (s->depth - 1) > PT_NLDS;
+    for (int j0 = 0; j0 < count; j0 += (int)batch_blocks) {
+        ptd::PassDesc pd;
+        pd.block_begin = block_begin; pd.block_stride = block_stride; pd.j0 = j0;
+        pd.num_blocks = (count - j0 < batch_blocks) ? count - j0 : (int)batch_blocks;
+        pd.blocks_x = blocks_x; pd.samples_per_block = (int32_t)spb; pd.num_lights = num_lights;
+        pd.inv_prob = 1.0f / prm->termination_prob;
+        if (c->count) { if (ovf) launch_integrate<true, true>(s, trav, ss, prm, cam, pd); else launch_integrate<true, false>(s, trav, ss, prm, cam, pd); }
+        else { if (ovf) launch_integrate<false, true>(s, trav, ss, prm, cam, pd); else launch_integrate<false, false>(s, trav, ss, prm, cam, pd); }
+        if (prm->sobol_block) {
+            HIP_TRY(hipMemsetAsync(c->d_counters + 3, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(k_accum_sobol, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum, c->d_spill, c->d_counters);
+            hipLaunchKernelGGL(k_apply_spill, dim3(1), dim3(64), 0, c->stream, *prm, c->d_spill, d_accum, c->d_counters);
+        } else {
+            hipLaunchKernelGGL(k_accum_gauss, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_render_pass(ptgpu_scene* s, const ptgpu_params* prm, const ptgpu_camera* cam, const ptgpu_light* lights, int32_t num_lights,
+                                 int32_t block_begin, int32_t block_end, int32_t block_stride, float* accum) {
+    if (!s || !prm || !accum) return fail(PTGPU_E_INVALID, "NULL argument");
+    int rc = check_params(prm);
+    if (rc != PTGPU_OK) return rc;
+    ptgpu_context* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)prm->width * prm->height * 16;
+    float* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpyAsync(d, accum, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = ptgpu_render_pass_dev(s, prm, cam, lights, num_lights, block_begin, block_end, block_stride, d);
+        if (rc == PTGPU_OK) e = hipMemcpyAsync(accum, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (rc != PTGPU_OK) return rc;
+    if (e != hipSuccess) return fail(PTGPU_E_HIP, "render pass: %s", hipGetErrorString(e));
+    unsigned long long ovf = 0;
+    HIP_TRY(hipMemcpy(&ovf, c->d_counters + 4, sizeof ovf, hipMemcpyDeviceToHost));
+    if (ovf) return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples did not fit the spill list", ovf);
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_resolve_dev(ptgpu_context* c, const float* d_accum, int32_t width, int32_t height, float* d_out_rgba) {
+    if (!c || !d_accum || !d_out_rgba) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (width <= 0 || height <= 0) return fail(PTGPU_E_INVALID, "image size %dx%d", width, height);
+    HIP_TRY(hipSetDevice(c->device));
+    const long long n = (long long)width * height;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_accum), n,
+                       reinterpret_cast<float4*>(d_out_rgba));
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;
 }
