@@ -838,7 +838,7 @@ static void launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const p
     const long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_PT_OVERSUB", 1);
     if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL((k_integrate<COUNT, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
-                       c->d_counters, env_int("PTGPU_PT_SERVICE", 24));
+                       c->d_counters, env_int("PTGPU_PT_SERVICE", 32));
 }
 
 extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, const ptgpu_camera* cam, const ptgpu_light* lights, int32_t num_lights,

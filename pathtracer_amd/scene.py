@@ -128,6 +128,20 @@ def value_noise_texture(seed, size=256, octaves=4, normal_map=False):
     return out
 
 
+def head_standin_textures(mesh, size=1600):
+    """Procedural stand-ins (seeded value noise, size x size RGBA8) for the six maps head.mtl names.  Three of them are
+    missing from the reference checkout (lambertian.png, normal.png, concrete2.png) and none may be read on the
+    GPU box, so every map is generated: same count, size and roles (map_Kd -> diffuse, map_bump -> tangent-space normal).
+    Returns (textures, name -> index)."""
+    textures, index = [], {}
+    for m in mesh["materials"]:
+        for name, is_normal in ((m["map_kd"], False), (m["map_bump"], True)):
+            if name and name not in index:
+                index[name] = len(textures)
+                textures.append(value_noise_texture(17 + 2 * len(textures) + (0 if is_normal else 1), size, normal_map=is_normal))
+    return textures, index
+
+
 def grid_scene(nx=8, ny=8, seed=1, jitter=0.3):
     """Small random triangle soup (tetra-ish fans on a jittered grid) for fast parity tests. Returns pos [n,3,3]."""
     rng = np.random.RandomState(seed)
