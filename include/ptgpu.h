@@ -134,6 +134,9 @@ const char* ptgpu_last_error(void);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream. */
 int ptgpu_set_stream(ptgpu_context* ctx, void* hip_stream);
 int ptgpu_sync(ptgpu_context* ctx);
+/* *out_done = 1 when everything enqueued on the context's stream has finished, else 0.  Replaces the completion poll of
+ * PathTraceRenderer::checkFinish (m_launcher.getNumFinished() == getNumTasks(), src/PathTraceRenderer.cpp:878). */
+int ptgpu_query(ptgpu_context* ctx, int* out_done);
 /* device memory for callers that have no allocator of their own (the C++ host classes) */
 int ptgpu_malloc(ptgpu_context* ctx, uint64_t bytes, void** out_dev);
 int ptgpu_free(ptgpu_context* ctx, void* dev);

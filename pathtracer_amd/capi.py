@@ -77,6 +77,7 @@ SIGNATURES = [
     ("ptgpu_last_error", C.c_char_p, []),
     ("ptgpu_set_stream", C.c_int, [_P, _P]),
     ("ptgpu_sync", C.c_int, [_P]),
+    ("ptgpu_query", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("ptgpu_malloc", C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     ("ptgpu_free", C.c_int, [_P, _P]),
     ("ptgpu_memcpy_h2d", C.c_int, [_P, _P, _P, C.c_uint64]),

@@ -119,6 +119,14 @@ extern "C" int ptgpu_sync(ptgpu_context* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PTGPU_OK;
 }
+extern "C" int ptgpu_query(ptgpu_context* c, int* out_done) {
+    if (!c || !out_done) return fail(PTGPU_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = hipStreamQuery(c->stream);
+    if (e != hipSuccess && e != hipErrorNotReady) return fail(PTGPU_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+    *out_done = (e == hipSuccess) ? 1 : 0;
+    return PTGPU_OK;
+}
 extern "C" int ptgpu_malloc(ptgpu_context* c, uint64_t bytes, void** out) {
     if (!c || !out) return fail(PTGPU_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));

@@ -1,0 +1,171 @@
+#include "PathTraceRenderer.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+namespace FW {
+
+// defaults of the tunables (reference src/PathTraceRenderer.cpp:15-28)
+bool PathTraceRenderer::debugVis = false;
+bool PathTraceRenderer::m_bilinearFiltering = true;
+bool PathTraceRenderer::m_depthOfField = false;
+bool PathTraceRenderer::m_normalMapped = false;
+bool PathTraceRenderer::m_sobolBlock = false;
+bool PathTraceRenderer::m_whitted = false;
+float PathTraceRenderer::m_aperture = 0.0f;
+float PathTraceRenderer::m_attenuation = 1.0f;
+float PathTraceRenderer::m_filterWidth = 1.0f;
+float PathTraceRenderer::m_focalDistance = 0.5f;
+float PathTraceRenderer::m_intensity = 1.0f;
+float PathTraceRenderer::m_terminationProbability = 0.2f;
+int PathTraceRenderer::m_NumAaRays = 4;
+int PathTraceRenderer::m_numLightRays = 32;
+
+PathTraceRenderer::PathTraceRenderer() {}
+PathTraceRenderer::~PathTraceRenderer() {
+    try { stop(); } catch (...) {}
+}
+
+// What tracePath derives from the camera for every sample (reference src/PathTraceRenderer.cpp:244-248, 271, 286-291, 398),
+// computed once per render.
+ptgpu_camera makeCameraPod(const CameraControls& cam, int width, int height) {
+    ptgpu_camera out;
+    Mat4f projection = Mat4f::fitToView(Vec2f(-1, -1), Vec2f(2, 2), Vec2f(Vec2i(width, height))) * cam.getCameraToClip();
+    Mat4f invP = (projection * cam.getWorldToCamera()).inverted();
+    std::memcpy(out.invP, invP.m, 64);
+    Vec3f f = cam.getForward(), c0 = cam.getOrientation().getCol(0), c1 = cam.getOrientation().getCol(1);
+    std::memcpy(out.forward, &f, 12);
+    std::memcpy(out.orient_col0, &c0, 12);
+    std::memcpy(out.orient_col1, &c1, 12);
+    out.far_ = cam.getFar();
+    return out;
+}
+
+ptgpu_params PathTraceRenderer::currentParams() const {
+    ptgpu_params p{};
+    Vec2i size = m_context.m_destImage ? m_context.m_destImage->getSize() : Vec2i(0, 0);
+    p.width = size.x; p.height = size.y;
+    p.bounces = m_context.m_bounces;
+    p.num_aa_rays = m_NumAaRays;
+    p.sobol_block = m_sobolBlock; p.bilinear = m_bilinearFiltering; p.normal_mapped = m_normalMapped;
+    p.depth_of_field = m_depthOfField; p.whitted = m_whitted; p.num_light_rays = m_numLightRays;
+    p.use_alpha = (m_context.m_rt && m_context.m_rt->useAlpha) ? 1 : 0;
+    p.pass_seed = m_passSeed;
+    p.aperture = m_aperture; p.attenuation = m_attenuation; p.filter_width = m_filterWidth;
+    p.focal_distance = m_focalDistance; p.intensity = m_intensity; p.termination_prob = m_terminationProbability;
+    return p;
+}
+
+void PathTraceRenderer::launchPass() {
+    ptgpu_params p = currentParams();
+    PT_GPU(ptgpu_render_pass_dev(m_context.m_rt->deviceScene(), &p, &m_cameraPod, m_lightPods.data(), (int32_t)m_lightPods.size(), m_blockBegin, -1,
+                                 m_blockStride, m_accum.ptr()));
+    ++m_passSeed;  // stands in for the reference's process-global seed counter (:689-691): every pass draws new samples
+    m_passInFlight = true;
+}
+
+void PathTraceRenderer::startPathTracingProcess(const MeshWithColors* scene, std::vector<AreaLight>* lights, RayTracer* rt, Image* dest,
+                                                int bounces, const CameraControls& camera) {
+    FW_ASSERT(!m_context.m_bForceExit);
+    if (!rt || !dest || !lights || lights->empty()) throw GpuError("startPathTracingProcess: tracer, destination image and at least one light are required");
+    if (m_running) stop();
+    m_context.m_bForceExit = false;
+    m_context.m_bResidual = false;
+    m_context.m_camera = &camera;
+    m_context.m_rt = rt;
+    m_context.m_scene = scene;
+    m_context.m_lights = lights;
+    m_context.m_light = &(*lights)[0];
+    m_context.m_pass = 0;
+    m_context.m_bounces = bounces;
+    m_context.m_image.reset(new Image(dest->getSize(), ImageFormat::RGBA_Vec4f));
+    m_context.m_destImage = dest;
+
+    // the reference's block list (:813-841); the device numbers blocks the same way (row-major)
+    m_context.m_blocks.clear();
+    const int bs = 32, w = dest->getSize().x, h = dest->getSize().y;
+    for (int y = 0; y < (h + bs - 1) / bs; ++y)
+        for (int x = 0; x < (w + bs - 1) / bs; ++x)
+            m_context.m_blocks.push_back(PathTracerBlock{bs * x, bs * y, min(bs * x + bs, w) - bs * x, min(bs * y + bs, h) - bs * y});
+    dest->clear();
+
+    m_cameraPod = makeCameraPod(camera, w, h);
+    m_lightPods.clear();
+    for (const AreaLight& l : *lights) m_lightPods.push_back(l.toPod());
+    m_accum.resize((size_t)w * h * 4);
+    m_accum.zero();
+    m_resolved.resize((size_t)w * h * 4);
+
+    ptgpu_context* ctx = GpuDevice::instance().ctx();
+    PT_GPU(ptgpu_reset_counters(ctx));
+    m_context.start = std::chrono::steady_clock::now();
+    m_running = true;
+    launchPass();
+}
+
+void PathTraceRenderer::updatePicture(Image* dest) {
+    FW_ASSERT(m_context.m_image != 0);
+    FW_ASSERT(m_context.m_image->getSize() == dest->getSize());
+    FW_ASSERT(dest->getFormat() == ImageFormat::RGBA_Vec4f);
+    ptgpu_context* ctx = GpuDevice::instance().ctx();
+    const Vec2i size = dest->getSize();
+    // resolve + gamma on the device (reference :859-869), then one copy into the display image; stream order puts it after
+    // whatever part of the current pass has been enqueued, like the reference's UI thread reading a half-finished pass
+    PT_GPU(ptgpu_resolve_dev(ctx, m_accum.ptr(), size.x, size.y, m_resolved.ptr()));
+    m_resolved.download((float*)dest->getMutablePtr(), (size_t)size.x * size.y * 4);
+    m_accum.download((float*)m_context.m_image->getMutablePtr(), (size_t)size.x * size.y * 4);
+}
+
+void PathTraceRenderer::checkFinish() {
+    if (!m_running || !m_passInFlight) return;
+    ptgpu_context* ctx = GpuDevice::instance().ctx();
+    int done = 0;
+    PT_GPU(ptgpu_query(ctx, &done));
+    if (!done) return;
+    m_passInFlight = false;
+    ++m_context.m_pass;
+    float time = static_cast<float>(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - m_context.start).count()) * 0.001f;
+
+    // 1 ray = 1 raycast() call, counted on the device (reference src/RayTracer.cpp:192); fold it into the tracer's counter
+    ptgpu_counters c{};
+    PT_GPU(ptgpu_get_counters(ctx, &c));
+    PT_GPU(ptgpu_reset_counters(ctx));
+    m_context.m_rt->addRays((long long)c.rays);
+    m_TotalRays += (unsigned long long)m_context.m_rt->getRayCountLong();
+    m_raysPerSecond = time > 0.0f ? m_TotalRays / time : 0.0f;
+    m_context.m_rt->resetRayCounter();
+    if (m_printStats) {
+        if (time < 60.0f) std::printf("  Done! time: %5.2f s   ", time);
+        else std::printf("  Done! time: %5.2f min   ", time / 60.0f);
+        std::printf("Total Mrays: %6.1f (%5.2f Mrays/sec)\n", m_TotalRays / 1000000.0f, m_raysPerSecond / 1000000.0f);
+    }
+    if (!m_context.m_bForceExit && (m_maxPasses <= 0 || m_context.m_pass < m_maxPasses)) {
+        launchPass();
+        if (m_printStats) std::printf("Pass %d\n", m_context.m_pass);
+    } else {
+        m_running = false;
+        if (m_printStats && m_context.m_bForceExit) std::printf("\nStopped!\n");
+    }
+}
+
+void PathTraceRenderer::waitPass() {
+    if (!m_running || !m_passInFlight) return;
+    PT_GPU(ptgpu_sync(GpuDevice::instance().ctx()));
+    checkFinish();
+}
+
+void PathTraceRenderer::stop() {
+    m_context.m_bForceExit = true;
+    if (m_running) {
+        // a device pass cannot be cancelled half-way; it is short (the reference waits for its worker threads the same way)
+        if (m_passInFlight) {
+            PT_GPU(ptgpu_sync(GpuDevice::instance().ctx()));
+            checkFinish();
+        }
+        m_running = false;
+    }
+    m_context.m_bForceExit = false;
+}
+
+}  // namespace FW

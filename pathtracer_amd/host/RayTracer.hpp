@@ -34,6 +34,7 @@ public:
     void saveHierarchy(const char* filename, const std::vector<RTTriangle>& triangles);
 
     int getRayCount() { return (int)m_rayCount.load(); }
+    long long getRayCountLong() const { return m_rayCount.load(); }
     void resetRayCounter() { m_rayCount = 0; }
     void addRays(long long n) const { m_rayCount += n; }
 

@@ -9,6 +9,7 @@
 #include "AreaLight.hpp"
 #include "Bvh.hpp"
 #include "Md5.hpp"
+#include "PathTraceRenderer.hpp"
 #include "RayTracer.hpp"
 #include "util.hpp"
 
@@ -74,13 +75,7 @@ int pth_bvh_build(int n, const float* pos, int sah, int threads, int32_t* out_li
 void pth_camera_make(const float eye[3], const float fwd[3], const float up[3], float fov, float nearD, float farD, int width, int height,
                      ptgpu_camera* out) {
     CameraControls cam(Vec3f(eye[0], eye[1], eye[2]), Vec3f(fwd[0], fwd[1], fwd[2]), Vec3f(up[0], up[1], up[2]), fov, nearD, farD);
-    // exactly the product tracePath forms per sample (reference src/PathTraceRenderer.cpp:244-248), hoisted to once per render
-    Mat4f projection = Mat4f::fitToView(Vec2f(-1, -1), Vec2f(2, 2), Vec2f(Vec2i(width, height))) * cam.getCameraToClip();
-    Mat4f invP = (projection * cam.getWorldToCamera()).inverted();
-    std::memcpy(out->invP, invP.m, 64);
-    Vec3f f = cam.getForward(), c0 = cam.getOrientation().getCol(0), c1 = cam.getOrientation().getCol(1);
-    std::memcpy(out->forward, &f, 12); std::memcpy(out->orient_col0, &c0, 12); std::memcpy(out->orient_col1, &c1, 12);
-    out->far_ = cam.getFar();
+    *out = makeCameraPod(cam, width, height);
 }
 
 void pth_light_make(const float pos[3], const float orient_cols[9], const float size[2], const float E[3], float intensity, ptgpu_light* out) {
@@ -167,6 +162,45 @@ int pth_rt_raycast(void* h, const float* orig, const float* dir, int64_t n, int 
         }
     });
 }
+// PathTraceRenderer over the tracer: settings through the reference's setters, `passes` passes, then updatePicture.
+// out_accum / out_resolved: [h][w][4] floats (either may be NULL).  stats: [0] total rays, [1] passes done.
+int pth_pt_render(void* h, const float eye[3], const float fwd[3], const float up[3], float fov, float nearD, float farD, int width, int height,
+                  const ptgpu_light* lights, int num_lights, const ptgpu_params* prm, int passes, int block_begin, int block_stride,
+                  float* out_accum, float* out_resolved, uint64_t stats[2]) {
+    return guarded([&] {
+        TracerBox* b = static_cast<TracerBox*>(h);
+        CameraControls cam(Vec3f(eye[0], eye[1], eye[2]), Vec3f(fwd[0], fwd[1], fwd[2]), Vec3f(up[0], up[1], up[2]), fov, nearD, farD);
+        std::vector<AreaLight> ls;
+        for (int i = 0; i < num_lights; ++i) {
+            const ptgpu_light& p = lights[i];
+            AreaLight l(Vec3f(p.E[0], p.E[1], p.E[2]), Vec2f(p.size[0], p.size[1]), p.intensity);
+            Mat4f X;
+            std::memcpy(X.m, p.xform, 64);
+            l.setOrientation(X.getXYZ());
+            l.setPosition(X.getCol(3).getXYZ());
+            l.updatePower();
+            ls.push_back(l);
+        }
+        PathTraceRenderer r;
+        r.setAAmode(prm->sobol_block != 0); r.setAArays(prm->num_aa_rays); r.setAperture(prm->aperture); r.setAttenuation(prm->attenuation);
+        r.setBilinearFiltering(prm->bilinear != 0); r.setDOF(prm->depth_of_field != 0); r.setFilterWidth(prm->filter_width);
+        r.setFocalDistance(prm->focal_distance); r.setIntensity(prm->intensity); r.setLightRays(prm->num_light_rays);
+        r.setNormalMapped(prm->normal_mapped != 0); r.setTermination(prm->termination_prob); r.setWhitted(prm->whitted != 0);
+        r.setBlockSubset(block_begin, block_stride);
+        r.setPrintStats(false);
+        r.setMaxPasses(passes);
+        b->rt.useAlpha = prm->use_alpha != 0;
+        Image dest(Vec2i(width, height), ImageFormat::RGBA_Vec4f);
+        r.startPathTracingProcess(b->mesh.get(), &ls, &b->rt, &dest, prm->bounces, cam);
+        while (r.isRunning()) r.waitPass();
+        r.updatePicture(&dest);
+        size_t n = (size_t)width * height * 16;
+        if (out_accum) std::memcpy(out_accum, r.m_context.m_image->getPtr(), n);
+        if (out_resolved) std::memcpy(out_resolved, dest.getPtr(), n);
+        if (stats) { stats[0] = r.getTotalRays(); stats[1] = (uint64_t)r.m_context.m_pass; }
+    });
+}
+
 int pth_rt_ray_count(void* h) { return static_cast<TracerBox*>(h)->rt.getRayCount(); }
 void pth_rt_reset_ray_counter(void* h) { static_cast<TracerBox*>(h)->rt.resetRayCounter(); }
 

@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-from .capi import FLATNODE_DTYPE, Camera, Light, load_library
+from .capi import FLATNODE_DTYPE, Camera, Light, Params, load_library
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpthost.so")
@@ -47,6 +47,8 @@ def lib():
         L.pth_rt_load_hierarchy.argtypes = [_P, C.c_char_p]
         L.pth_rt_mesh_md5.argtypes = [_P, _P]
         L.pth_rt_raycast.argtypes = [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P]
+        L.pth_pt_render.argtypes = [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int, C.POINTER(Params), C.c_int,
+                                    C.c_int, C.c_int, _P, _P, _P]
         L.pth_rt_ray_count.argtypes = [_P]
         L.pth_rt_reset_ray_counter.argtypes = [_P]
         _lib = L
@@ -163,3 +165,16 @@ class HostRayTracer:
 
     def reset_ray_counter(self):
         lib().pth_rt_reset_ray_counter(self.h)
+
+    def path_trace(self, params, lights, passes=1, eye=(0.0, 0.0, 0.48), forward=(0.0, -0.1, -1.0), up=(0.0, 1.0, 0.0), fov_deg=70.0, near=0.001,
+                   far=3.0, block_begin=0, block_stride=1):
+        """FW::PathTraceRenderer::startPathTracingProcess ... checkFinish x passes ... updatePicture on this tracer.
+        Returns (accumulation image, resolved display image, total rays, passes done)."""
+        w, h = params.width, params.height
+        accum, resolved = np.empty((h, w, 4), np.float32), np.empty((h, w, 4), np.float32)
+        st = np.zeros(2, np.uint64)
+        e, f, u = _f32(eye), _f32(forward), _f32(up)
+        larr = (Light * len(lights))(*lights)
+        _check(lib().pth_pt_render(self.h, e.ctypes.data, f.ctypes.data, u.ctypes.data, fov_deg, near, far, w, h, C.cast(larr, _P), len(lights),
+                                   C.byref(params), passes, block_begin, block_stride, accum.ctypes.data, resolved.ctypes.data, st.ctypes.data))
+        return accum, resolved, int(st[0]), int(st[1])

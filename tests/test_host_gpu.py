@@ -62,3 +62,23 @@ def test_hierarchy_cache_roundtrip(host_rt, head, oracle, tmp_path):
     o, d = oracle.gen_primary(cam, 200, 100)
     g, c = host_rt.raycast(o, d, False), oracle.raycast(head["sd"], o, d, False)
     assert np.array_equal(g["id"], c["id"]) and np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+
+
+def test_host_path_trace_renderer_matches_oracle(host_rt, head, oracle):
+    """FW::PathTraceRenderer (start -> checkFinish per pass -> updatePicture) over the device pass: two passes accumulate exactly
+    what two oracle passes with pass seeds 0 and 1 accumulate; the display image is the oracle's resolve; rays are counted."""
+    w, h = 80, 48
+    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=True)
+    lights = [scene.make_light()]
+    host_rt.reset_ray_counter()  # like the reference, a pass adds whatever the tracer counted since its last reset
+    accum, resolved, rays, passes = host_rt.path_trace(prm, lights, passes=2)
+    assert passes == 2
+    cam = scene.make_camera(width=w, height=h)
+    c, total = None, 0
+    for seed in (0, 1):
+        prm.pass_seed = seed
+        c, ctr = oracle.render_pass(head["sd"], prm, cam, lights, accum=c, nthreads=8)
+        total += ctr["rays"]
+    assert np.array_equal(accum.view(np.uint32), c.view(np.uint32))
+    assert np.array_equal(resolved.view(np.uint32), oracle.resolve(c, libm=False).view(np.uint32))
+    assert rays == total
