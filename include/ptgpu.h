@@ -193,6 +193,13 @@ int ptgpu_render_pass(ptgpu_scene* scene, const ptgpu_params* params, const ptgp
  * pixels pass through undivided.  Both pointers are DEVICE pointers, [height][width][4] floats. */
 int ptgpu_resolve_dev(ptgpu_context* ctx, const float* d_accum, int32_t width, int32_t height, float* d_out_rgba);
 
+/* rtIntersect.inl intersect_triangle1 (src/rtIntersect.inl:215-259; two-sided Moller-Trumbore, EPSILON 1e-9) for n independent
+ * (ray, triangle) pairs, HOST pointers: orig/dir/v0/v1/v2 [n][3].  out_hit = 1/0; t,u,v are written as the reference leaves them on a
+ * hit and as 0 on a miss.  The reference includes this file but never calls it (its live test is intersect_woop); kept as a separate
+ * entry point, not as a traversal variant, so that traversal parity is defined by what the reference executes. */
+int ptgpu_intersect_triangle1_batch(ptgpu_context* ctx, const float* orig, const float* dir, const float* v0, const float* v1,
+                                    const float* v2, int64_t n, int32_t* out_hit, float* out_t, float* out_u, float* out_v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,7 @@ SIGNATURES = [
     ("ptgpu_render_pass_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("ptgpu_render_pass", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("ptgpu_resolve_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    ("ptgpu_intersect_triangle1_batch", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
 ]
 
 _lib = None
@@ -196,6 +197,15 @@ class Context:
         finally:
             self.free(d_in)
             self.free(d_out)
+
+    def intersect_triangle1(self, orig, direction, v0, v1, v2):
+        """rtIntersect.inl intersect_triangle1 for n (ray, triangle) pairs -> (hit int32[n], t, u, v float32[n])."""
+        a = [_f32(x).reshape(-1, 3) for x in (orig, direction, v0, v1, v2)]
+        n = a[0].shape[0]
+        hit, t, u, v = np.empty(n, np.int32), np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+        _check(self.lib.ptgpu_intersect_triangle1_batch(self.handle, *(x.ctypes.data for x in a), n, hit.ctypes.data, t.ctypes.data,
+                                                        u.ctypes.data, v.ctypes.data))
+        return hit, t, u, v
 
     def gen_primary_dev(self, cam, width, height, d_orig, d_dir):
         _check(self.lib.ptgpu_gen_primary_dev(self.handle, C.byref(cam), width, height, d_orig, d_dir))

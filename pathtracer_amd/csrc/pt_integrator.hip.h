@@ -246,12 +246,17 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
         if (n_run == 0 && n_wait == 0) break;  // exhausted and every lane idle
         if (n_wait > 0 && (n_run == 0 || n_wait >= service_threshold || n_wait >= n_run)) {
             // ------------------------------------------------------------------ service section
-            bool do_hit = false, do_bounce = false, do_finish = false;
+            bool do_hit = false, do_bounce = false, do_finish = false, do_wshadow = false, do_wfinal = false;
             int hit_tri = -1, hit_mat = 0;
             float hit_u = 0.0f, hit_v = 0.0f;
             if (!tr.alive && ps.stage != ST_IDLE) {
                 int next_ctl = 0;  // 0 none, 1 fixed-bounce check, 2 roulette entry, 3 roulette check
-                if (ps.stage == ST_SH) {
+                if (ps.stage == ST_SH && ps.mode == 3) {
+                    // traceWhitted's light-ray loop (reference :614-637): count unoccluded disk samples
+                    if (tr.pmin < 0) ps.terminate += 1.0f;
+                    ps.bounce += 1;
+                    if (ps.bounce < prm.num_light_rays) do_wshadow = true; else do_wfinal = true;
+                } else if (ps.stage == ST_SH) {
                     if (tr.pmin < 0) {
                         // unoccluded: reference :346-376 / :416-450 / :500-534
                         const ptgpu_light& Lt = lights[ps.li];
@@ -298,6 +303,52 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                     if (ps.terminate > prm.termination_prob) { ps.mode = 2; do_bounce = true; }
                     else do_finish = true;
                 }
+            }
+            if (do_hit && prm.whitted) {
+                // traceWhitted, reference :608-613: hit set-up, then num_light_rays shadow rays towards disk samples of ONE light
+                ps.O = tr.o + tr.tmin * tr.d;
+                ps.V = normalize(tr.d);
+                get_texture_parameters(SS, prm, hit_tri, hit_mat, hit_u, hit_v, ps.diffuse, ps.N, ps.specular);
+                ps.gloss = SS.materials[hit_mat].glossiness;
+                ps.normalization = (ps.gloss + 2.0f) / (4.0f * PI * (2.0f - ptm_pow(2.0f, -ps.gloss / 2.0f)));
+                ps.li = get_light_to_sample(ps.O, lights, pd.num_lights, ps.R);
+                ps.terminate = 0.0f;  // "shadow": number of unoccluded light rays
+                ps.bounce = 0;        // light-ray index
+                ps.mode = 3;
+                do_wshadow = true;
+                do_hit = false;
+            }
+            if (do_wshadow) {
+                // AreaLight::sampleDisk, src/AreaLight.cpp:87-108, with dimension 0
+                const ptgpu_light& Lt = lights[ps.li];
+                int r = ps.R.getS32(1, 1000);
+                float sa, sb;
+                sobol32x2((uint32_t)(ps.base + r), 4u, sa, sb);
+                float a = (2.0f * sa - 1.0f) * Lt.size[0];
+                float b = (2.0f * sb - 1.0f) * Lt.size[1];
+                float x, y;
+                map_to_disk(a, b, x, y);
+                F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * x + light_col(Lt, 1) * y;
+                ps.L = Pl - ps.O;
+                F3 D = normalize(ps.L);
+                tr.begin(TS, ps.O + 0.0001f * D, ps.L, true, lds_lane);  // origin offset along D here, not N (:634)
+                n_rays += 1;
+                ps.stage = ST_SH;
+            }
+            if (do_wfinal) {
+                // reference :639-656
+                const ptgpu_light& Lt = lights[ps.li];
+                F3 L = light_col(Lt, 3) - ps.O;
+                F3 D = normalize(L);
+                float d = length(L);
+                float attenuation = prm.intensity / (prm.attenuation * ptm_pow(d, 2.0f) + prm.attenuation * d + 0.5f);
+                F3 H = normalize(D - ps.V);
+                F3 color = ps.diffuse * sel_max(0.0f, dot(ps.N, D));
+                color = color + ps.specular * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
+                color = color * attenuation;
+                color = color * (ps.terminate / (float)prm.num_light_rays);
+                ps.Ei = color;
+                do_finish = true;
             }
             if (do_hit) {
                 // reference :300-344 (first hit) and :403-414 / :486-498 (bounce hits)
@@ -419,7 +470,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         if (prm.depth_of_field) {
                             F3 Rn = normalize(Rd);
                             F3 Pn = f3(cam.forward[0], cam.forward[1], cam.forward[2]);
-                            float Pd = prm.focal_distance / sel_max(0.01f, dot(Rn, Pn));
+                            float Pd = prm.whitted ? prm.focal_distance / dot(Rn, Pn) : prm.focal_distance / sel_max(0.01f, dot(Rn, Pn));  // :589 vs :272
                             F3 Rf = Ro + Pd * Rn;
                             float xr, yr;
                             float a = ps.R.getF32(-1.0f, 1.0f);

@@ -825,7 +825,7 @@ static int check_params(const ptgpu_params* p) {
     if (p->width <= 0 || p->height <= 0) return fail(PTGPU_E_INVALID, "image size %dx%d", p->width, p->height);
     if ((long long)p->width * p->height > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "image too large");
     if (p->num_aa_rays < 1 || p->num_aa_rays > 65536) return fail(PTGPU_E_INVALID, "num_aa_rays %d out of range [1,65536]", p->num_aa_rays);
-    if (p->whitted) return fail(PTGPU_E_UNSUPPORTED, "Whitted mode (traceWhitted) is not on the device path yet");
+    if (p->whitted && p->num_light_rays < 1) return fail(PTGPU_E_INVALID, "num_light_rays must be >= 1 in Whitted mode");
     if (p->bounces < 0 && !(p->termination_prob > 0.0f)) return fail(PTGPU_E_INVALID, "termination_prob must be > 0 with Russian roulette");
     if (!p->sobol_block && !(p->filter_width > 0.0f)) return fail(PTGPU_E_INVALID, "filter_width must be > 0");
     return PTGPU_OK;
@@ -942,5 +942,82 @@ extern "C" int ptgpu_resolve_dev(ptgpu_context* c, const float* d_accum, int32_t
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_accum), n,
                        reinterpret_cast<float4*>(d_out_rgba));
     HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rtIntersect.inl intersect_triangle1 (reference src/rtIntersect.inl:215-259): two-sided Moller-Trumbore on raw vertex
+// positions.  Dead code in the reference (included by RayTracer.cpp:7, never called -- the live test is Woop),
+// provided as a batch kernel so that the test north_star names exists on the device, pinned bit-exactly on goldens produced by
+// the reference's own source (tests/golden/rtintersect_golden.json).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_intersect_triangle1(const float* __restrict__ orig, const float* __restrict__ dir, const float* __restrict__ v0,
+                                      const float* __restrict__ v1, const float* __restrict__ v2, long long n, int32_t* __restrict__ hit,
+                                      float* __restrict__ ot, float* __restrict__ ou, float* __restrict__ ov) {
+    using namespace ptd;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float EPSILON = 0.000000001f;
+    F3 o = ld3(orig + i * 3), d = ld3(dir + i * 3), a = ld3(v0 + i * 3);
+    F3 edge1 = ld3(v1 + i * 3) - a, edge2 = ld3(v2 + i * 3) - a;
+    F3 pvec = cross(d, edge2);
+    float det = dot(edge1, pvec);
+    float u = 0.0f, v = 0.0f, t = 0.0f;
+    F3 tvec, qvec = f3(0, 0, 0);
+    bool ok = true;
+    if (det > EPSILON) {
+        tvec = o - a;
+        u = dot(tvec, pvec);
+        if (u < 0.0f || u > det) ok = false;
+        if (ok) {
+            qvec = cross(tvec, edge1);
+            v = dot(d, qvec);
+            if (v < 0.0f || u + v > det) ok = false;
+        }
+    } else if (det < -EPSILON) {
+        tvec = o - a;
+        u = dot(tvec, pvec);
+        if (u > 0.0f || u < det) ok = false;
+        if (ok) {
+            qvec = cross(tvec, edge1);
+            v = dot(d, qvec);
+            if (v > 0.0f || u + v < det) ok = false;
+        }
+    } else
+        ok = false;
+    if (ok) {
+        float inv_det = 1.f / det;
+        t = dot(edge2, qvec) * inv_det;
+        u *= inv_det;
+        v *= inv_det;
+    }
+    hit[i] = ok ? 1 : 0;
+    ot[i] = ok ? t : 0.0f; ou[i] = ok ? u : 0.0f; ov[i] = ok ? v : 0.0f;
+}
+
+extern "C" int ptgpu_intersect_triangle1_batch(ptgpu_context* c, const float* orig, const float* dir, const float* v0, const float* v1,
+                                               const float* v2, int64_t n, int32_t* out_hit, float* out_t, float* out_u, float* out_v) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    if (n < 0) return fail(PTGPU_E_INVALID, "n < 0");
+    if (n == 0) return PTGPU_OK;
+    if (!orig || !dir || !v0 || !v1 || !v2 || !out_hit || !out_t || !out_u || !out_v) return fail(PTGPU_E_INVALID, "NULL array");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_in = nullptr;
+    float* d_out = nullptr;
+    hipError_t e = hipMalloc(&d_in, (size_t)n * 15 * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * 4 * 4);
+    const float* src[5] = {orig, dir, v0, v1, v2};
+    for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipMemcpyAsync(d_in + (size_t)k * n * 3, src[k], (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_intersect_triangle1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_in, d_in + n * 3, d_in + n * 6,
+                           d_in + n * 9, d_in + n * 12, (long long)n, reinterpret_cast<int32_t*>(d_out), d_out + n, d_out + 2 * n, d_out + 3 * n);
+        e = hipGetLastError();
+    }
+    void* dst[4] = {out_hit, out_t, out_u, out_v};
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipMemcpyAsync(dst[k], d_out + (size_t)k * n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_in) hipFree(d_in);
+    if (d_out) hipFree(d_out);
+    if (e != hipSuccess) return fail(PTGPU_E_HIP, "intersect_triangle1 batch: %s", hipGetErrorString(e));
     return PTGPU_OK;
 }

@@ -157,3 +157,17 @@ def test_rejects_bad_params(head_gpu):
         head_gpu.render_pass(scene.make_params(width=32, height=32, num_aa_rays=0), cam, lights)
     with pytest.raises(capi.PtgpuError):
         head_gpu.render_pass(scene.make_params(width=32, height=32, bounces=-1, termination_prob=0.0), cam, lights)
+
+
+@pytest.mark.parametrize("sobol_block", [True, False])
+def test_whitted_mode_exact(soup_gpu, textured_soup, oracle, sobol_block):
+    """traceWhitted (reference :553-660) with AreaLight::sampleDisk shadow rays, two lights, depth of field (no max(0.01,.) here)."""
+    w, h = 64, 64
+    cam, lights = _soup_view(w, h)
+    prm = scene.make_params(width=w, height=h, num_aa_rays=2, sobol_block=sobol_block, whitted=True, num_light_rays=5, bilinear=True,
+                            normal_mapped=True, depth_of_field=True, aperture=0.01, focal_distance=2.0, attenuation=0.7, intensity=1.3,
+                            filter_width=1.2, pass_seed=8)
+    g = soup_gpu.render_pass(prm, cam, lights)
+    c, ctr = oracle.render_pass(textured_soup, prm, cam, lights, nthreads=8)
+    assert c[..., :3].max() > 0.01 and ctr["rays"] > w * h * 2
+    _assert_image_exact(g, c, "whitted sobol_block=%s" % sobol_block)
