@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (tools/run_profiles.sh) into profiles/<tag>_pmc_summary.json (+ profiles/traffic.json):
+per kernel, per launch: duration from the kernel trace and the mean of every collected counter.
+HBM traffic follows MI355X_MICROARCH.md "HBM": bytes = FETCH_SIZE*1024 (x2 on gfx950: the counter tallies 128-B requests as 64 B
+for wide reads) + WRITE_SIZE*1024; both raw and corrected values are kept."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    out = defaultdict(lambda: {"launches": 0})
+    for f in glob.glob(os.path.join(base, "trace", "*", "*_kernel_trace.csv")):
+        dur = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for k, v in dur.items():
+            out[k]["launches"] = len(v)
+            out[k]["avg_duration_us"] = sum(v) / len(v) / 1e3
+            out[k]["min_duration_us"] = min(v) / 1e3
+    for f in glob.glob(os.path.join(base, "*", "*", "*_counter_collection.csv")):
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            out[short(r["Kernel_Name"])].setdefault("vgpr", int(r.get("VGPR_Count", 0) or 0))
+            out[short(r["Kernel_Name"])].setdefault("lds_bytes", int(r.get("LDS_Block_Size", 0) or 0))
+        for k, cs in acc.items():
+            for c, v in cs.items():
+                out[k][c] = sum(v) / len(v)
+    for k, d in out.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            d["hbm_bytes_raw"] = (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+            d["hbm_bytes_corrected"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+        if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d and d["TCC_HIT_sum"] + d["TCC_MISS_sum"] > 0:
+            d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+        if "SQ_ACTIVE_INST_VALU" in d and "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"] > 0:
+            d["valu_active_frac_of_wave_cycles"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
+        if "SQ_THREAD_CYCLES_VALU" in d and "SQ_ACTIVE_INST_VALU" in d and d["SQ_ACTIVE_INST_VALU"] > 0:
+            d["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
+    keep = {k: v for k, v in out.items() if k.startswith("k_")}
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    json.dump(keep, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    traffic = {}
+    for k, v in keep.items():
+        if k.startswith("k_raycast_step<false") and "hbm_bytes_corrected" in v:
+            traffic["k_raycast_closest_hbm_bytes_per_launch"] = v["hbm_bytes_corrected"]
+            traffic["k_raycast_closest_hbm_bytes_per_launch_raw"] = v["hbm_bytes_raw"]
+            traffic["k_raycast_closest_l2_hit_rate"] = v.get("l2_hit_rate")
+        if k.startswith("k_integrate") and "hbm_bytes_corrected" in v:
+            traffic["k_integrate_hbm_bytes_per_launch"] = v["hbm_bytes_corrected"]
+            traffic["k_integrate_l2_hit_rate"] = v.get("l2_hit_rate")
+    traffic["source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM note)" % tag
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
+    for k, v in sorted(keep.items()):
+        print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
+
+
+if __name__ == "__main__":
+    main()
