@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptgpu.so")
+LIB_PATH = os.environ.get("PTGPU_LIB", os.path.join(_HERE, "libptgpu.so"))  # PTGPU_LIB: A/B builds of the same ABI
 
 
 class PtgpuError(RuntimeError):

@@ -204,8 +204,19 @@ __device__ __forceinline__ int block_sobol_base(int idx, uint32_t pass_seed) {
     return idx * mul + add;
 }
 
+// Diagnostic build only (-DPT_STAMPS): per-wave cycle and lane-count sums per loop section, added into counters[8..].
+// Sections: 0 control+classification, 1 shade, 2 hit set-up, 3 whitted shadow, 4 bounce, 5 new sample, 6 traversal step.
+// counters[8+3k] = cycles, [9+3k] = invocations, [10+3k] = lanes served.  Never quote this build's run time.
+#ifdef PT_STAMPS
+#define PT_STAMP_BEGIN() const long long st_t0_ = (long long)__builtin_amdgcn_s_memtime()
+#define PT_STAMP_END(k, lanes) do { st_cyc[k] += (long long)__builtin_amdgcn_s_memtime() - st_t0_; st_inv[k] += 1; st_lanes[k] += (lanes); } while (0)
+#else
+#define PT_STAMP_BEGIN() do {} while (0)
+#define PT_STAMP_END(k, lanes) do {} while (0)
+#endif
+
 // per-lane path state between two service rounds
-enum : int { ST_IDLE = 0, ST_EXT = 1, ST_SH = 2 };
+enum : int { ST_IDLE = 0, ST_EXT = 1, ST_SH = 2, ST_BOUNCE = 3, ST_WSHADOW = 4 };
 
 struct PathState {
     F3 O, N, V, diffuse, specular, throughput, Ei, emission, L;
@@ -220,10 +231,11 @@ struct PathState {
 template <bool COUNT, int NLDS, bool OVF, int BLOCK>
 __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene& SS, const ptgpu_params& prm, const ptgpu_camera& cam,
                                           const ptgpu_light* __restrict__ lights, const PassDesc& pd, float4* __restrict__ rad,
-                                          unsigned long long* counters, uint2* lds_lane, int service_threshold) {
+                                          unsigned long long* counters, uint2* lds_lane, uint2* gl_lane, int service_threshold) {
     const int lane = threadIdx.x & 63;
     Trav<true, COUNT, NLDS, OVF> tr;
     tr.reset_counts();
+    tr.attach(lds_lane, gl_lane);
     tr.alive = false;
     PathState ps;
     ps.stage = ST_IDLE;
@@ -239,269 +251,308 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
     const float div_x = 1.0f / (float)prm.width, div_y = 1.0f / (float)prm.height;
     const float PI = 3.14159265358979323846f;
 
-    for (;;) {
-        const unsigned long long running = __ballot(tr.alive);
-        const unsigned long long waiting = __ballot(!tr.alive && (ps.stage != ST_IDLE || !exhausted));
-        const int n_run = __popcll(running), n_wait = __popcll(waiting);
-        if (n_run == 0 && n_wait == 0) break;  // exhausted and every lane idle
-        if (n_wait > 0 && (n_run == 0 || n_wait >= service_threshold || n_wait >= n_run)) {
-            // ------------------------------------------------------------------ service section
-            bool do_hit = false, do_bounce = false, do_finish = false, do_wshadow = false, do_wfinal = false;
-            int hit_tri = -1, hit_mat = 0;
-            float hit_u = 0.0f, hit_v = 0.0f;
-            if (!tr.alive && ps.stage != ST_IDLE) {
-                int next_ctl = 0;  // 0 none, 1 fixed-bounce check, 2 roulette entry, 3 roulette check
-                if (ps.stage == ST_SH && ps.mode == 3) {
-                    // traceWhitted's light-ray loop (reference :614-637): count unoccluded disk samples
-                    if (tr.pmin < 0) ps.terminate += 1.0f;
-                    ps.bounce += 1;
-                    if (ps.bounce < prm.num_light_rays) do_wshadow = true; else do_wfinal = true;
-                } else if (ps.stage == ST_SH) {
-                    if (tr.pmin < 0) {
-                        // unoccluded: reference :346-376 / :416-450 / :500-534
-                        const ptgpu_light& Lt = lights[ps.li];
-                        F3 D = normalize(ps.L);
-                        F3 Nl = -light_col(Lt, 2);
-                        if (dot(ps.N, ps.V) > 0.0f) ps.N = ps.N * -1.0f;
-                        float cos_theta = sel_max(0.0f, dot(ps.N, D));
-                        float cos_theta_l = sel_max(0.0f, dot(Nl, -D));
-                        float d = length(ps.L);
-                        float inv_d = sel_min(1.0f / (d * d), 100000.0f);
-                        float inv_pdf = sel_min(1.0f / ps.pdf, 100000.0f);
-                        F3 H = normalize(D - ps.V);
-                        F3 color = ps.diffuse;
-                        color = color + ps.specular * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
-                        const float invPi = 0.31830988618379f;
-                        F3 c;
-                        if (ps.mode == 0) c = color * invPi * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
-                        else if (ps.mode == 1) c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
-                        else c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf * pd.inv_prob;
-                        ps.Ei = ps.Ei + c;
-                    }
-                    next_ctl = 1;
-                    if (ps.mode == 1) ps.bounce += 1;
-                    if (ps.mode == 2) { ps.terminate = ps.R.getF32(0.0f, 1.0f); ps.bounce += 1; next_ctl = 3; }
-                } else {  // ST_EXT
-                    if (tr.pmin >= 0) {
-                        do_hit = true;
-                        float4 rec = TS.tris[(size_t)tr.pmin * 4 + 3];
-                        hit_tri = __float_as_int(rec.x);
-                        hit_mat = __float_as_int(rec.w);
-                        hit_u = tr.umin; hit_v = tr.vmin;
-                    } else if (ps.mode == 1) next_ctl = 2;  // miss inside the fixed-bounce loop: `break`, then the roulette section
-                    else do_finish = true;                  // primary miss (Ei = 0) or miss inside the roulette loop
-                }
-                if (next_ctl == 1) {
-                    if (ps.bounce < bounces) { ps.mode = 1; do_bounce = true; }
-                    else next_ctl = 2;
-                }
-                if (next_ctl == 2) {
-                    if (prm.bounces < 0) { ps.terminate = ps.R.getF32(0.0f, 1.0f); next_ctl = 3; }
-                    else do_finish = true;
-                }
-                if (next_ctl == 3) {
-                    if (ps.terminate > prm.termination_prob) { ps.mode = 2; do_bounce = true; }
-                    else do_finish = true;
-                }
-            }
-            if (do_hit && prm.whitted) {
-                // traceWhitted, reference :608-613: hit set-up, then num_light_rays shadow rays towards disk samples of ONE light
-                ps.O = tr.o + tr.tmin * tr.d;
-                ps.V = normalize(tr.d);
-                get_texture_parameters(SS, prm, hit_tri, hit_mat, hit_u, hit_v, ps.diffuse, ps.N, ps.specular);
-                ps.gloss = SS.materials[hit_mat].glossiness;
-                ps.normalization = (ps.gloss + 2.0f) / (4.0f * PI * (2.0f - ptm_pow(2.0f, -ps.gloss / 2.0f)));
-                ps.li = get_light_to_sample(ps.O, lights, pd.num_lights, ps.R);
-                ps.terminate = 0.0f;  // "shadow": number of unoccluded light rays
-                ps.bounce = 0;        // light-ray index
-                ps.mode = 3;
-                do_wshadow = true;
-                do_hit = false;
-            }
-            if (do_wshadow) {
-                // AreaLight::sampleDisk, src/AreaLight.cpp:87-108, with dimension 0
-                const ptgpu_light& Lt = lights[ps.li];
-                int r = ps.R.getS32(1, 1000);
-                float sa, sb;
-                sobol32x2((uint32_t)(ps.base + r), 4u, sa, sb);
-                float a = (2.0f * sa - 1.0f) * Lt.size[0];
-                float b = (2.0f * sb - 1.0f) * Lt.size[1];
-                float x, y;
-                map_to_disk(a, b, x, y);
-                F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * x + light_col(Lt, 1) * y;
-                ps.L = Pl - ps.O;
-                F3 D = normalize(ps.L);
-                tr.begin(TS, ps.O + 0.0001f * D, ps.L, true, lds_lane);  // origin offset along D here, not N (:634)
-                n_rays += 1;
-                ps.stage = ST_SH;
-            }
-            if (do_wfinal) {
-                // reference :639-656
-                const ptgpu_light& Lt = lights[ps.li];
-                F3 L = light_col(Lt, 3) - ps.O;
-                F3 D = normalize(L);
-                float d = length(L);
-                float attenuation = prm.intensity / (prm.attenuation * ptm_pow(d, 2.0f) + prm.attenuation * d + 0.5f);
-                F3 H = normalize(D - ps.V);
-                F3 color = ps.diffuse * sel_max(0.0f, dot(ps.N, D));
-                color = color + ps.specular * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
-                color = color * attenuation;
-                color = color * (ps.terminate / (float)prm.num_light_rays);
-                ps.Ei = color;
-                do_finish = true;
-            }
-            if (do_hit) {
-                // reference :300-344 (first hit) and :403-414 / :486-498 (bounce hits)
-                F3 point = tr.o + tr.tmin * tr.d;
-                if (ps.mode == 0) {
-                    ps.gloss = SS.materials[hit_mat].glossiness;
-                    ps.normalization = (ps.gloss + 2.0f) / (4.0f * PI * (2.0f - ptm_pow(2.0f, -ps.gloss / 2.0f)));
-                    ps.bounce = 0;
-                    ps.throughput = f3(1.0f, 1.0f, 1.0f);
-                    ps.V = normalize(tr.d);
-                }
-                ps.O = point;
-                get_texture_parameters(SS, prm, hit_tri, hit_mat, hit_u, hit_v, ps.diffuse, ps.N, ps.specular);
-                ps.li = get_light_to_sample(ps.O, lights, pd.num_lights, ps.R);
-                const ptgpu_light& Lt = lights[ps.li];
-                // AreaLight::sample, src/AreaLight.cpp:69-85
-                int dim = 4 + 4 * sobol_bounce_dim(ps.bounce);
-                int r = ps.R.getS32(1, 10000);
-                float sa, sb;
-                sobol32x2((uint32_t)(ps.base + r), (unsigned)dim, sa, sb);
-                float lx = (2.0f * sa - 1.0f) * Lt.size[0];
-                float ly = (2.0f * sb - 1.0f) * Lt.size[1];
-                F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * lx + light_col(Lt, 1) * ly;
-                ps.pdf = 1.0f / (4.0f * Lt.size[0] * Lt.size[1]);
-                ps.L = Pl - ps.O;
-                if (ps.mode == 0) ps.emission = f3(Lt.E[0], Lt.E[1], Lt.E[2]) * prm.intensity;  // once per path (:341)
-                tr.begin(TS, ps.O + 0.0001f * ps.N, ps.L, true, lds_lane);
-                n_rays += 1;
-                ps.stage = ST_SH;
-            }
-            if (do_bounce) {
-                // reference :391-401 / :473-484; drawCosineWeightedDirection :57-73 (RNG peeked, not advanced)
-                int dim = 2 + 4 * sobol_bounce_dim(ps.bounce);
-                int rnd = ps.R.peekS32(1, 1234);
-                float sa, sb;
-                sobol32x2((uint32_t)(ps.base + rnd), (unsigned)dim, sa, sb);
-                float a = 2.0f * sa - 1.0f, b = 2.0f * sb - 1.0f;
-                float x, y;
-                map_to_disk(a, b, x, y);
-                float z = sqrtf(1 - x * x - y * y);
-                ps.V = normalize(basis_times(ps.N, f3(x, y, z)));
-                ps.throughput = ps.throughput * ps.diffuse;
-                tr.begin(TS, ps.O + 0.0001f * ps.N, cam.far_ * ps.V, false, lds_lane);
-                n_rays += 1;
-                ps.stage = ST_EXT;
-            }
-            if (do_finish) {
-                float4 o;
-                o.x = ps.Ei.x; o.y = ps.Ei.y; o.z = ps.Ei.z; o.w = ps.aux;
-                rad[ps.sid] = o;
-                ps.stage = ST_IDLE;
-                ps.sid = -1;
-            }
-            // ---- pull new samples for idle lanes (ballot + prefix rank over the wave's current chunk)
-            unsigned long long need = __ballot(ps.stage == ST_IDLE);
-            while (need != 0ull && !exhausted) {
-                if (next >= end) {
-                    round += 1;
-                    const long long cbase = (round * total_waves + (wave_id + round * 997) % total_waves) * 64;
-                    if (cbase >= total) { exhausted = true; break; }
-                    next = cbase;
-                    end = next + 64 < total ? next + 64 : total;
-                }
-                const int avail = (int)(end - next);
-                const int rank = __popcll(need & ((1ull << lane) - 1ull));
-                if (ps.stage == ST_IDLE && rank < avail) {
-                    const long long sid = next + rank;
-                    const int jj = (int)(sid / pd.samples_per_block);
-                    const int s = (int)(sid - (long long)jj * pd.samples_per_block);
-                    const int idx = pd.block_begin + (pd.j0 + jj) * pd.block_stride;
-                    const int bx = (idx % pd.blocks_x) * 32, by = (idx / pd.blocks_x) * 32;
-                    const int bw = (bx + 32 < prm.width) ? 32 : prm.width - bx;
-                    const int bh = (by + 32 < prm.height) ? 32 : prm.height - by;
-                    const int base = block_sobol_base(idx, prm.pass_seed);
-                    bool valid;
-                    float px, py;
-                    int sbase;
-                    if (prm.sobol_block) {  // reference :706-727
-                        const int i = s;
-                        valid = i < bw * bh * prm.num_aa_rays;
-                        float sa, sb;
-                        sobol32x2((uint32_t)(base + i), 0u, sa, sb);
-                        px = (float)bx + (float)bw * sa;
-                        py = (float)by + (float)bh * sb;
-                        sbase = base + i;
-                        ps.R.seed((uint32_t)idx, prm.pass_seed, (uint32_t)i, 0u);
-                        int pixel_x = (int)floorf(px); if (pixel_x > prm.width - 1) pixel_x = prm.width - 1;
-                        int pixel_y = (int)floorf(py); if (pixel_y > prm.height - 1) pixel_y = prm.height - 1;
-                        ps.aux = __int_as_float(pixel_y * prm.width + pixel_x);  // global pixel index; accumulate checks the block
-                    } else {  // reference :743-779
-                        const int i = s / prm.num_aa_rays, k = s - i * prm.num_aa_rays;
-                        valid = i < bw * bh;
-                        const int pixel_x = bx + (i % bw), pixel_y = by + (i / bw);
-                        float sa, sb;
-                        sobol32x2((uint32_t)(base + i + k), 0u, sa, sb);
-                        float a = prm.filter_width * (sa - 0.5f) + 0.5f;
-                        float b = prm.filter_width * (sb - 0.5f) + 0.5f;
-                        px = (float)pixel_x + a;
-                        py = (float)pixel_y + b;
-                        if (px < 0.0f) px *= -1.0f;
-                        if (py < 0.0f) py *= -1.0f;
-                        if (px > (float)prm.width) px -= a;
-                        if (py > (float)prm.height) py -= b;
-                        sbase = base + i;
-                        ps.R.seed((uint32_t)idx, prm.pass_seed, (uint32_t)i, (uint32_t)k);
-                        const float fs = 2.0f / prm.filter_width;
-                        ps.aux = gauss(fs * (a - 0.5f), fs * (b - 0.5f));
-                    }
-                    if (valid) {
-                        float x = px * div_x * 2.0f - 1.0f;
-                        float y = py * div_y * -2.0f + 1.0f;
-                        // camera ray, reference :244-292
-                        F4 Roh = mul44(cam.invP, x, y, 0.0f, 1.0f);
-                        float iw0 = 1.0f / Roh.w;
-                        F3 Ro = f3(Roh.x * iw0, Roh.y * iw0, Roh.z * iw0);
-                        F4 Rdh = mul44(cam.invP, x, y, 1.0f, 1.0f);
-                        float iw1 = 1.0f / Rdh.w;
-                        F3 Rd = f3(Rdh.x * iw1, Rdh.y * iw1, Rdh.z * iw1) - Ro;
-                        if (prm.depth_of_field) {
-                            F3 Rn = normalize(Rd);
-                            F3 Pn = f3(cam.forward[0], cam.forward[1], cam.forward[2]);
-                            float Pd = prm.whitted ? prm.focal_distance / dot(Rn, Pn) : prm.focal_distance / sel_max(0.01f, dot(Rn, Pn));  // :589 vs :272
-                            F3 Rf = Ro + Pd * Rn;
-                            float xr, yr;
-                            float a = ps.R.getF32(-1.0f, 1.0f);
-                            float b = ps.R.getF32(-1.0f, 1.0f);
-                            map_to_disk(a, b, xr, yr);
-                            F3 up = f3(cam.orient_col0[0], cam.orient_col0[1], cam.orient_col0[2]);
-                            F3 right = f3(cam.orient_col1[0], cam.orient_col1[1], cam.orient_col1[2]);
-                            Ro = Ro + prm.aperture * (yr * up + xr * right);
-                            Rd = cam.far_ * normalize(Rf - Ro);
-                        }
-                        ps.sid = sid;
-                        ps.base = sbase;
-                        ps.mode = 0;
-                        ps.bounce = 0;
-                        ps.Ei = f3(0.0f, 0.0f, 0.0f);
-                        tr.begin(TS, Ro, Rd, false, lds_lane);
-                        n_rays += 1;
-                        ps.stage = ST_EXT;
-                    } else {
-                        ps.stage = ST_EXT;  // placeholder so that this lane is not handed a second id in this while-loop pass
-                        ps.sid = -2;
-                    }
-                }
-                const int n_need = __popcll(need);
-                next += n_need < avail ? n_need : avail;
-                need = __ballot(ps.stage == ST_IDLE);
-            }
-            if (ps.sid == -2) { ps.stage = ST_IDLE; ps.sid = -1; }  // padded sample id: nothing to trace
+    // finish a sample: its radiance leaves through rad[], the lane becomes idle
+    auto finish = [&]() {
+        float4 o;
+        o.x = ps.Ei.x; o.y = ps.Ei.y; o.z = ps.Ei.z; o.w = ps.aux;
+        rad[ps.sid] = o;
+        ps.stage = ST_IDLE;
+        ps.sid = -1;
+    };
+    // loop control of tracePath between two rays: 1 = fixed-bounce loop test (:389), 2 = roulette entry (:466-468),
+    // 3 = roulette loop test (:471).  Leaves the lane waiting for a bounce ray (ST_BOUNCE) or finishes the sample.
+    auto advance = [&](int next_ctl) {
+        if (next_ctl == 1) {
+            if (ps.bounce < bounces) { ps.mode = 1; ps.stage = ST_BOUNCE; return; }
+            next_ctl = 2;
         }
-        if (tr.alive) tr.step(TS);
+        if (next_ctl == 2) {
+            if (prm.bounces < 0) { ps.terminate = ps.R.getF32(0.0f, 1.0f); next_ctl = 3; }
+            else { finish(); return; }
+        }
+        if (ps.terminate > prm.termination_prob) { ps.mode = 2; ps.stage = ST_BOUNCE; }
+        else finish();
+    };
+
+#ifdef PT_STAMPS
+    long long st_cyc[7] = {0, 0, 0, 0, 0, 0, 0}, st_inv[7] = {0, 0, 0, 0, 0, 0, 0}, st_lanes[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+    // Whitted: next disk sample of the chosen light and its shadow ray (shared tail of the hit and shade blocks)
+    auto whitted_shadow = [&]() {
+        // AreaLight::sampleDisk, src/AreaLight.cpp:87-108, with dimension 0
+        const ptgpu_light& Lt = lights[ps.li];
+        int r = ps.R.getS32(1, 1000);
+        float sa, sb;
+        sobol32x2((uint32_t)(ps.base + r), 4u, sa, sb);
+        float a = (2.0f * sa - 1.0f) * Lt.size[0];
+        float b = (2.0f * sb - 1.0f) * Lt.size[1];
+        float x, y;
+        map_to_disk(a, b, x, y);
+        F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * x + light_col(Lt, 1) * y;
+        ps.L = Pl - ps.O;
+        F3 D = normalize(ps.L);
+        tr.begin(TS, ps.O + 0.0001f * D, ps.L, true);  // origin offset along D here, not N (:634)
+        n_rays += 1;
+        ps.stage = ST_SH;
+    };
+
+    // Wave-uniform scheduling.  A lane is traversing (alive) or waits for ONE of three service blocks:
+    //   H  hit set-up after a closest-hit ray that hit  (texture parameters, light choice, light sample, shadow ray)
+    //   S  shade after a shadow ray + loop control + bounce set-up (also lanes whose bounce ray missed and go on to roulette)
+    //   N  retire / new sample
+    // The wave runs the block most lanes wait for once that count reaches service_threshold (or exceeds the traversing lanes),
+    // so each block runs with many of its lanes; otherwise all traversing lanes take one step.  Classification is redone only
+    // when a ray has finished or a block has run.
+    bool dirty = true;
+    unsigned long long prev_alive = 0ull;
+    for (;;) {
+        const unsigned long long alive_mask = __ballot(tr.alive);
+        if (dirty || alive_mask != prev_alive) {
+            PT_STAMP_BEGIN();
+            dirty = false;
+            // cheap control: closest-hit rays that missed
+            if (!tr.alive && ps.stage == ST_EXT && tr.pmin < 0) {
+                if (ps.mode == 1) advance(2);  // miss inside the fixed-bounce loop: `break`, then the roulette section
+                else finish();                 // primary miss (Ei = 0), or miss inside the roulette loop
+            }
+            const int nA = __popcll(alive_mask);
+            const int nH = __popcll(__ballot(!tr.alive && ps.stage == ST_EXT));
+            const int nS = __popcll(__ballot((!tr.alive && ps.stage == ST_SH) || ps.stage == ST_BOUNCE));
+            const int nN = exhausted ? 0 : __popcll(__ballot(ps.stage == ST_IDLE));
+            if (nA == 0 && nH + nS + nN == 0) break;  // sample range exhausted and every lane idle
+            int best = nH;
+            if (nS > best) best = nS;
+            if (nN > best) best = nN;
+            const bool run = best > 0 && (best >= service_threshold || best >= nA);
+            PT_STAMP_END(0, nH + nS + nN);
+            if (run && nH == best) {
+                PT_STAMP_BEGIN();
+                if (!tr.alive && ps.stage == ST_EXT) {
+                    // hit set-up: reference :300-344 (first hit), :403-414 / :486-498 (bounce hits), :608-613 (Whitted)
+                    const float4 rec = TS.tris[(size_t)tr.pmin * 4 + 3];
+                    const int hit_tri = __float_as_int(rec.x), hit_mat = __float_as_int(rec.w);
+                    const bool first = ps.mode == 0;
+                    if (first || prm.whitted) {
+                        ps.gloss = SS.materials[hit_mat].glossiness;
+                        ps.normalization = (ps.gloss + 2.0f) / (4.0f * PI * (2.0f - ptm_pow(2.0f, -ps.gloss / 2.0f)));
+                        ps.bounce = 0;
+                        ps.throughput = f3(1.0f, 1.0f, 1.0f);
+                        ps.V = normalize(tr.d);
+                    }
+                    ps.O = tr.o + tr.tmin * tr.d;
+                    get_texture_parameters(SS, prm, hit_tri, hit_mat, tr.umin, tr.vmin, ps.diffuse, ps.N, ps.specular);
+                    ps.li = get_light_to_sample(ps.O, lights, pd.num_lights, ps.R);
+                    if (prm.whitted) {
+                        ps.terminate = 0.0f;  // "shadow": number of unoccluded light rays; ps.bounce = light-ray index
+                        ps.mode = 3;
+                        ps.stage = ST_WSHADOW;
+                    } else {
+                        const ptgpu_light& Lt = lights[ps.li];
+                        // AreaLight::sample, src/AreaLight.cpp:69-85
+                        int dim = 4 + 4 * sobol_bounce_dim(ps.bounce);
+                        int r = ps.R.getS32(1, 10000);
+                        float sa, sb;
+                        sobol32x2((uint32_t)(ps.base + r), (unsigned)dim, sa, sb);
+                        float lx = (2.0f * sa - 1.0f) * Lt.size[0];
+                        float ly = (2.0f * sb - 1.0f) * Lt.size[1];
+                        F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * lx + light_col(Lt, 1) * ly;
+                        ps.pdf = 1.0f / (4.0f * Lt.size[0] * Lt.size[1]);
+                        ps.L = Pl - ps.O;
+                        if (first) ps.emission = f3(Lt.E[0], Lt.E[1], Lt.E[2]) * prm.intensity;  // once per path (:341)
+                        tr.begin(TS, ps.O + 0.0001f * ps.N, ps.L, true);
+                        n_rays += 1;
+                        ps.stage = ST_SH;
+                    }
+                    if (ps.stage == ST_WSHADOW) whitted_shadow();
+                }
+                PT_STAMP_END(2, nH);
+                dirty = true;
+            } else if (run && nS == best) {
+                PT_STAMP_BEGIN();
+                if (!tr.alive && ps.stage == ST_SH) {
+                    if (ps.mode == 3) {
+                        // traceWhitted's light-ray loop (reference :614-637): count unoccluded disk samples
+                        if (tr.pmin < 0) ps.terminate += 1.0f;
+                        ps.bounce += 1;
+                        if (ps.bounce < prm.num_light_rays) ps.stage = ST_WSHADOW;
+                        else {
+                            // reference :639-656
+                            const ptgpu_light& Lt = lights[ps.li];
+                            F3 L = light_col(Lt, 3) - ps.O;
+                            F3 D = normalize(L);
+                            float d = length(L);
+                            float attenuation = prm.intensity / (prm.attenuation * ptm_pow(d, 2.0f) + prm.attenuation * d + 0.5f);
+                            F3 H = normalize(D - ps.V);
+                            F3 color = ps.diffuse * sel_max(0.0f, dot(ps.N, D));
+                            color = color + ps.specular * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
+                            color = color * attenuation;
+                            color = color * (ps.terminate / (float)prm.num_light_rays);
+                            ps.Ei = color;
+                            finish();
+                        }
+                    } else {
+                        if (tr.pmin < 0) {
+                            // unoccluded: reference :346-376 / :416-450 / :500-534
+                            const ptgpu_light& Lt = lights[ps.li];
+                            F3 D = normalize(ps.L);
+                            F3 Nl = -light_col(Lt, 2);
+                            if (dot(ps.N, ps.V) > 0.0f) ps.N = ps.N * -1.0f;
+                            float cos_theta = sel_max(0.0f, dot(ps.N, D));
+                            float cos_theta_l = sel_max(0.0f, dot(Nl, -D));
+                            float d = length(ps.L);
+                            float inv_d = sel_min(1.0f / (d * d), 100000.0f);
+                            float inv_pdf = sel_min(1.0f / ps.pdf, 100000.0f);
+                            F3 H = normalize(D - ps.V);
+                            F3 color = ps.diffuse;
+                            color = color + ps.specular * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
+                            const float invPi = 0.31830988618379f;
+                            F3 c;
+                            if (ps.mode == 0) c = color * invPi * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
+                            else if (ps.mode == 1) c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
+                            else c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf * pd.inv_prob;
+                            ps.Ei = ps.Ei + c;
+                        }
+                        if (ps.mode == 2) { ps.terminate = ps.R.getF32(0.0f, 1.0f); ps.bounce += 1; advance(3); }
+                        else { if (ps.mode == 1) ps.bounce += 1; advance(1); }
+                    }
+                }
+                if (ps.stage == ST_WSHADOW) whitted_shadow();
+                if (ps.stage == ST_BOUNCE) {
+                    // reference :391-401 / :473-484; drawCosineWeightedDirection :57-73 (RNG peeked, not advanced)
+                    int dim = 2 + 4 * sobol_bounce_dim(ps.bounce);
+                    int rnd = ps.R.peekS32(1, 1234);
+                    float sa, sb;
+                    sobol32x2((uint32_t)(ps.base + rnd), (unsigned)dim, sa, sb);
+                    float a = 2.0f * sa - 1.0f, b = 2.0f * sb - 1.0f;
+                    float x, y;
+                    map_to_disk(a, b, x, y);
+                    float z = sqrtf(1 - x * x - y * y);
+                    ps.V = normalize(basis_times(ps.N, f3(x, y, z)));
+                    ps.throughput = ps.throughput * ps.diffuse;
+                    tr.begin(TS, ps.O + 0.0001f * ps.N, cam.far_ * ps.V, false);
+                    n_rays += 1;
+                    ps.stage = ST_EXT;
+                }
+                PT_STAMP_END(1, nS);
+                dirty = true;
+            } else if (run) {
+                PT_STAMP_BEGIN();
+                // ---- pull new samples for idle lanes (ballot + prefix rank over the wave's current chunk)
+                unsigned long long need = __ballot(ps.stage == ST_IDLE);
+                while (need != 0ull && !exhausted) {
+                    if (next >= end) {
+                        round += 1;
+                        const long long cbase = (round * total_waves + (wave_id + round * 997) % total_waves) * 64;
+                        if (cbase >= total) { exhausted = true; break; }
+                        next = cbase;
+                        end = next + 64 < total ? next + 64 : total;
+                    }
+                    const int avail = (int)(end - next);
+                    const int rank = __popcll(need & ((1ull << lane) - 1ull));
+                    if (ps.stage == ST_IDLE && rank < avail) {
+                        const long long sid = next + rank;
+                        const int jj = (int)(sid / pd.samples_per_block);
+                        const int s = (int)(sid - (long long)jj * pd.samples_per_block);
+                        const int idx = pd.block_begin + (pd.j0 + jj) * pd.block_stride;
+                        const int bx = (idx % pd.blocks_x) * 32, by = (idx / pd.blocks_x) * 32;
+                        const int bw = (bx + 32 < prm.width) ? 32 : prm.width - bx;
+                        const int bh = (by + 32 < prm.height) ? 32 : prm.height - by;
+                        const int base = block_sobol_base(idx, prm.pass_seed);
+                        bool valid;
+                        float px, py;
+                        int sbase;
+                        if (prm.sobol_block) {  // reference :706-727
+                            const int i = s;
+                            valid = i < bw * bh * prm.num_aa_rays;
+                            float sa, sb;
+                            sobol32x2((uint32_t)(base + i), 0u, sa, sb);
+                            px = (float)bx + (float)bw * sa;
+                            py = (float)by + (float)bh * sb;
+                            sbase = base + i;
+                            ps.R.seed((uint32_t)idx, prm.pass_seed, (uint32_t)i, 0u);
+                            int pixel_x = (int)floorf(px); if (pixel_x > prm.width - 1) pixel_x = prm.width - 1;
+                            int pixel_y = (int)floorf(py); if (pixel_y > prm.height - 1) pixel_y = prm.height - 1;
+                            ps.aux = __int_as_float(pixel_y * prm.width + pixel_x);  // global pixel index; accumulate checks the block
+                        } else {  // reference :743-779
+                            const int i = s / prm.num_aa_rays, k = s - i * prm.num_aa_rays;
+                            valid = i < bw * bh;
+                            const int pixel_x = bx + (i % bw), pixel_y = by + (i / bw);
+                            float sa, sb;
+                            sobol32x2((uint32_t)(base + i + k), 0u, sa, sb);
+                            float a = prm.filter_width * (sa - 0.5f) + 0.5f;
+                            float b = prm.filter_width * (sb - 0.5f) + 0.5f;
+                            px = (float)pixel_x + a;
+                            py = (float)pixel_y + b;
+                            if (px < 0.0f) px *= -1.0f;
+                            if (py < 0.0f) py *= -1.0f;
+                            if (px > (float)prm.width) px -= a;
+                            if (py > (float)prm.height) py -= b;
+                            sbase = base + i;
+                            ps.R.seed((uint32_t)idx, prm.pass_seed, (uint32_t)i, (uint32_t)k);
+                            const float fs = 2.0f / prm.filter_width;
+                            ps.aux = gauss(fs * (a - 0.5f), fs * (b - 0.5f));
+                        }
+                        if (valid) {
+                            float x = px * div_x * 2.0f - 1.0f;
+                            float y = py * div_y * -2.0f + 1.0f;
+                            // camera ray, reference :244-292
+                            F4 Roh = mul44(cam.invP, x, y, 0.0f, 1.0f);
+                            float iw0 = 1.0f / Roh.w;
+                            F3 Ro = f3(Roh.x * iw0, Roh.y * iw0, Roh.z * iw0);
+                            F4 Rdh = mul44(cam.invP, x, y, 1.0f, 1.0f);
+                            float iw1 = 1.0f / Rdh.w;
+                            F3 Rd = f3(Rdh.x * iw1, Rdh.y * iw1, Rdh.z * iw1) - Ro;
+                            if (prm.depth_of_field) {
+                                F3 Rn = normalize(Rd);
+                                F3 Pn = f3(cam.forward[0], cam.forward[1], cam.forward[2]);
+                                float Pd = prm.whitted ? prm.focal_distance / dot(Rn, Pn) : prm.focal_distance / sel_max(0.01f, dot(Rn, Pn));  // :589 vs :272
+                                F3 Rf = Ro + Pd * Rn;
+                                float xr, yr;
+                                float a = ps.R.getF32(-1.0f, 1.0f);
+                                float b = ps.R.getF32(-1.0f, 1.0f);
+                                map_to_disk(a, b, xr, yr);
+                                F3 up = f3(cam.orient_col0[0], cam.orient_col0[1], cam.orient_col0[2]);
+                                F3 right = f3(cam.orient_col1[0], cam.orient_col1[1], cam.orient_col1[2]);
+                                Ro = Ro + prm.aperture * (yr * up + xr * right);
+                                Rd = cam.far_ * normalize(Rf - Ro);
+                            }
+                            ps.sid = sid;
+                            ps.base = sbase;
+                            ps.mode = 0;
+                            ps.bounce = 0;
+                            ps.Ei = f3(0.0f, 0.0f, 0.0f);
+                            tr.begin(TS, Ro, Rd, false);
+                            n_rays += 1;
+                            ps.stage = ST_EXT;
+                        } else {
+                            ps.stage = ST_EXT;  // placeholder so that this lane is not handed a second id in this while-loop pass
+                            ps.sid = -2;
+                        }
+                    }
+                    const int n_need = __popcll(need);
+                    next += n_need < avail ? n_need : avail;
+                    need = __ballot(ps.stage == ST_IDLE);
+                }
+                if (ps.sid == -2) { ps.stage = ST_IDLE; ps.sid = -1; }  // padded sample id: nothing to trace
+                PT_STAMP_END(5, nN);
+                dirty = true;
+            }
+            prev_alive = __ballot(tr.alive);
+        }
+        {
+            PT_STAMP_BEGIN();
+            if (tr.alive) tr.step(TS);
+            PT_STAMP_END(6, __popcll(alive_mask));
+        }
     }
+#ifdef PT_STAMPS
+    if (lane == 0)
+        for (int k = 0; k < 7; ++k) {
+            atomicAdd(&counters[8 + 3 * k], (unsigned long long)st_cyc[k]);
+            atomicAdd(&counters[9 + 3 * k], (unsigned long long)st_inv[k]);
+            atomicAdd(&counters[10 + 3 * k], (unsigned long long)st_lanes[k]);
+        }
+#endif
     // 1 ray = 1 raycast() call (reference src/RayTracer.cpp:192)
     unsigned long long wr = n_rays;
     for (int off = 32; off > 0; off >>= 1) wr += __shfl_down(wr, off);

@@ -22,7 +22,7 @@
 //    leaf, alpha-texture id or -1, material id}.
 //  * per-lane stack of {node ref, entry distance} pairs: the first NLDS entries live in LDS laid
 //    out [entry][lane] (conflict-free ds_read_b64/ds_write_b64), deeper entries spill to a
-//    private array.  Depth is bounded by the validated tree depth (<= 64 like the reference's
+//    per-wave region of global memory laid out the same way (rarely touched).  Depth is bounded by the validated tree depth (<= 64 like the reference's
 //    int nodesToVisit[64]).
 #pragma once
 #include "pt_device.hip.h"
@@ -76,26 +76,28 @@ __device__ __forceinline__ void slab(float nx, float ny, float nz, float fx, flo
 template <int NLDS, bool OVF>
 struct LaneStack {
     uint2* lds;  // this lane's slot of entry 0; entry e is lds[e * 64]
-    uint2 ovf[OVF ? (64 - NLDS) : 1];
+    uint2* gl;   // OVF only: this lane's slot of overflow entry 0 in global memory; entry e is gl[e * 64]
     int sp;
     __device__ __forceinline__ void push(int ref, float tentry) {
         uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tentry));
         if (!OVF || sp < NLDS) lds[sp * 64] = e;
-        else ovf[sp - NLDS] = e;
+        else gl[(sp - NLDS) * 64] = e;
         ++sp;
     }
     __device__ __forceinline__ uint2 pop() {
         --sp;
         if (!OVF || sp < NLDS) return lds[sp * 64];
-        return ovf[sp - NLDS];
+        return gl[(sp - NLDS) * 64];
     }
 };
+// bytes of global overflow space one wave needs (entries NLDS..63 for 64 lanes)
+template <int NLDS> constexpr size_t stack_overflow_bytes_per_wave() { return (size_t)(64 - NLDS) * 64 * sizeof(uint2); }
 
 // ANYHIT: occlusion flag of raycast().  ALPHA: alpha-texture cutout enabled and present in the scene.
 // COUNT: also count the reference's node visits / triangle tests (far children are then always pushed so
 // that the counts equal the CPU traversal's exactly; results are unchanged).
 template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
-__device__ __forceinline__ HitRec traverse(const TravScene& S, F3 o, F3 d, uint2* lds_lane, uint32_t& n_nodes, uint32_t& n_tris) {
+__device__ __forceinline__ HitRec traverse(const TravScene& S, F3 o, F3 d, uint2* lds_lane, uint2* gl_lane, uint32_t& n_nodes, uint32_t& n_tris) {
     HitRec best;
     best.id = -1; best.t = 3.402823466e+38f; best.u = 0.0f; best.v = 0.0f;
     if (S.list_size <= 0) return best;
@@ -108,6 +110,7 @@ __device__ __forceinline__ HitRec traverse(const TravScene& S, F3 o, F3 d, uint2
 
     LaneStack<NLDS, OVF> st;
     st.lds = lds_lane;
+    st.gl = gl_lane;
     st.sp = 0;
 
     int cur = S.root_ref;
@@ -235,13 +238,14 @@ struct Trav {
 
     __device__ __forceinline__ void reset_counts() { n_nodes = 0; n_tris = 0; }
 
-    __device__ __forceinline__ void begin(const TravScene& S, F3 o_, F3 d_, bool anyhit_, uint2* lds_lane) {
+    __device__ __forceinline__ void attach(uint2* lds_lane, uint2* gl_lane) { st.lds = lds_lane; st.gl = gl_lane; st.sp = 0; }
+
+    __device__ __forceinline__ void begin(const TravScene& S, F3 o_, F3 d_, bool anyhit_) {
         o = o_; d = d_; anyhit = anyhit_;
         tmin = 1.0f; umin = 0.0f; vmin = 0.0f; pmin = -1;
         inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
         signbits = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
-        st.lds = lds_lane;
         st.sp = 0;
         cur = S.root_ref;
         alive = false;

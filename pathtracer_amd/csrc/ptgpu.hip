@@ -51,8 +51,10 @@ struct ptgpu_context {
     ptgpu_light* d_lights = nullptr;
     std::vector<ptgpu_light> h_lights;  // what d_lights holds
     float4* d_spill = nullptr;
+    uint2* d_stack_ovf = nullptr;  // global-memory overflow of the per-lane traversal stacks (trees deeper than the LDS stack)
+    size_t stack_ovf_bytes = 0;
 };
-constexpr int CTR_WORDS = 8;
+constexpr int CTR_WORDS = 32;  // [0..2] public counters, [3..4] spill list, [8..28] diagnostic stamps (PT_STAMPS builds)
 constexpr int SPILL_CAPACITY = 1 << 16;
 
 struct ptgpu_scene {
@@ -103,6 +105,7 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     if (c->d_rad) hipFree(c->d_rad);
     if (c->d_lights) hipFree(c->d_lights);
     if (c->d_spill) hipFree(c->d_spill);
+    if (c->d_stack_ovf) hipFree(c->d_stack_ovf);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return PTGPU_OK;
@@ -175,6 +178,14 @@ extern "C" int ptgpu_get_counters(ptgpu_context* c, ptgpu_counters* out) {
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2];
+    return PTGPU_OK;
+}
+// Diagnostic (not declared in include/ptgpu.h): raw copy of all counter words, for PT_STAMPS builds.
+extern "C" int ptgpu_debug_counters(ptgpu_context* c, unsigned long long* out32) {
+    if (!c || !out32) return fail(PTGPU_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out32, c->d_counters, CTR_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PTGPU_OK;
 }
 extern "C" int ptgpu_reset_counters(ptgpu_context* c) {
@@ -365,43 +376,22 @@ extern "C" int ptgpu_scene_stats(const ptgpu_scene* s, uint64_t out_bytes[4], in
 // kernels
 // ------------------------------------------------------------------------------------------------
 constexpr int RC_BLOCK = 256;  // 4 waves
-constexpr int RC_NLDS = 16;    // stack entries per lane kept in LDS (8 KiB per wave)
 
-template <bool ANYHIT, bool ALPHA, bool COUNT, bool OVF>
-__global__ __launch_bounds__(RC_BLOCK) void k_raycast(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
-                                                      long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
-                                                      float* __restrict__ out_u, float* __restrict__ out_v, unsigned long long* counters) {
-    __shared__ uint2 lds_stack[RC_BLOCK / 64][RC_NLDS][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
-    uint32_t n_nodes = 0, n_tris = 0;
-    if (i < n) {
-        ptd::F3 o = ptd::ld3(orig + i * 3), d = ptd::ld3(dir + i * 3);
-        ptd::HitRec h = ptd::traverse<ANYHIT, ALPHA, COUNT, RC_NLDS, OVF>(S, o, d, &lds_stack[wave][0][lane], n_nodes, n_tris);
-        if (out_id) out_id[i] = h.id;
-        if (out_t) out_t[i] = h.t;
-        if (out_u) out_u[i] = h.u;
-        if (out_v) out_v[i] = h.v;
-    }
-    if (COUNT) {
-        atomicAdd(&counters[1], (unsigned long long)n_nodes);
-        atomicAdd(&counters[2], (unsigned long long)n_tris);
-    }
-}
-
-// Step-wise variant, one ray per lane for the lane's whole life (no refill).
-template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
+// One ray per lane for the lane's whole life (no refill), step-wise traverser.  Only built without stack overflow: a grid of
+// n/256 workgroups has no bounded set of waves to give overflow space to; deep trees use k_raycast_persist.
+template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS>
 __global__ __launch_bounds__(RC_BLOCK) void k_raycast_step(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
                                                            long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
                                                            float* __restrict__ out_u, float* __restrict__ out_v, unsigned long long* counters) {
     __shared__ uint2 lds_stack[RC_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
-    ptd::Trav<ALPHA, COUNT, NLDS, OVF> tr;
+    ptd::Trav<ALPHA, COUNT, NLDS, false> tr;
     tr.reset_counts();
+    tr.attach(&lds_stack[wave][0][lane], nullptr);
     tr.alive = false;
     if (i < n) {
-        tr.begin(S, ptd::ld3(orig + i * 3), ptd::ld3(dir + i * 3), ANYHIT, &lds_stack[wave][0][lane]);
+        tr.begin(S, ptd::ld3(orig + i * 3), ptd::ld3(dir + i * 3), ANYHIT);
         while (tr.alive) tr.step(S);
         ptd::HitRec h = tr.result(S);
         if (out_id) out_id[i] = h.id;
@@ -426,17 +416,17 @@ template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
 __global__ __launch_bounds__(RC_BLOCK) void k_raycast_persist(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
                                                               long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
                                                               float* __restrict__ out_u, float* __restrict__ out_v,
-                                                              unsigned long long* counters, int refill_threshold) {
+                                                              unsigned long long* counters, int refill_threshold, uint2* stack_ovf) {
     __shared__ uint2 lds_stack[RC_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint2* lds_lane = &lds_stack[wave][0][lane];
+    const long long total_waves = (long long)gridDim.x * (RC_BLOCK / 64);
+    const long long wave_id = (long long)blockIdx.x * (RC_BLOCK / 64) + wave;
     ptd::Trav<ALPHA, COUNT, NLDS, OVF> tr;
     tr.reset_counts();
+    tr.attach(&lds_stack[wave][0][lane], OVF ? stack_ovf + (size_t)wave_id * (64 - NLDS) * 64 + lane : nullptr);
     tr.alive = false;
     long long ray = -1;           // ray this lane currently owns
     long long next = 0, end = 0;  // wave-uniform: unassigned part of the wave's current chunk
-    const long long total_waves = (long long)gridDim.x * (RC_BLOCK / 64);
-    const long long wave_id = (long long)blockIdx.x * (RC_BLOCK / 64) + wave;
     long long round = -1;  // advanced before first use
     bool exhausted = false;       // wave-uniform
     for (;;) {
@@ -468,7 +458,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast_persist(ptd::TravScene S, 
                 int rank = __popcll(need & ((1ull << lane) - 1ull));  // position of this lane among the lanes that need a ray
                 if ((ray < 0) && (rank < avail)) {
                     ray = next + rank;
-                    tr.begin(S, ptd::ld3(orig + ray * 3), ptd::ld3(dir + ray * 3), ANYHIT, lds_lane);
+                    tr.begin(S, ptd::ld3(orig + ray * 3), ptd::ld3(dir + ray * 3), ANYHIT);
                 }
                 int taken = __popcll(need) < avail ? __popcll(need) : avail;
                 next += taken;
@@ -488,65 +478,66 @@ __global__ void k_add_rays(unsigned long long* counters, unsigned long long n) {
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], n);
 }
 
-// Kernel selection.  Defaults are the measured-best variant; PTGPU_RAYCAST_IMPL (0 = while-while, 1 = step-wise,
-// 2 = persistent step-wise with refill) and PTGPU_RAYCAST_NLDS (8 / 16 / 24 LDS stack entries per lane) exist for A/B
-// timing in one process (read at every launch).  Every variant produces identical hit records.
+// Kernel selection.  PTGPU_RAYCAST_IMPL (1 = step-wise, one ray per lane; 2 = persistent step-wise with refill) and
+// PTGPU_RAYCAST_NLDS (16 / 24 LDS stack entries per lane) exist for A/B timing in one process (read at every launch).  Every
+// variant produces identical hit records.  Trees deeper than the LDS stack always take the persistent kernel, whose bounded
+// set of waves owns a global-memory overflow region each.
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-struct RcConfig { int impl, nlds; };
-static RcConfig rc_config() {
-    RcConfig c = {env_int("PTGPU_RAYCAST_IMPL", 1), env_int("PTGPU_RAYCAST_NLDS", 24)};
-    return c;
+
+static int ensure_stack_overflow(ptgpu_context* c, size_t bytes) {
+    if (bytes <= c->stack_ovf_bytes) return PTGPU_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_stack_ovf) { HIP_TRY(hipFree(c->d_stack_ovf)); c->d_stack_ovf = nullptr; c->stack_ovf_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->d_stack_ovf, bytes));
+    c->stack_ovf_bytes = bytes;
+    return PTGPU_OK;
 }
 
 template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
-static int launch_rc_impl(ptgpu_scene* s, int impl, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
+static int launch_rc_persist(ptgpu_scene* s, const ptd::TravScene& trav, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
     ptgpu_context* c = s->ctx;
-    hipStream_t st = c->stream;
-    dim3 block(RC_BLOCK);
-    ptd::TravScene trav = s->trav;
-    trav.alpha_on = ALPHA ? 1 : 0;
-    if (impl == 2) {
-        long long want = (n + RC_CHUNK - 1) / RC_CHUNK;  // no more waves than chunks
-        long long blocks = (want + (RC_BLOCK / 64) - 1) / (RC_BLOCK / 64);
-        // a small multiple of the blocks resident at once (LDS-limited): long-lived waves, dispatcher-level balancing
-        static int per_cu = 0;
-        if (per_cu == 0) {
-            int v = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>, RC_BLOCK, 0) != hipSuccess || v < 1) v = 1;
-            per_cu = v;
-        }
-        long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_RAYCAST_OVERSUB", 2);
-        if (blocks > resident) blocks = resident;
-        hipLaunchKernelGGL((k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>), dim3((unsigned)blocks), block, 0, st, trav, o, d, n, id, t,
-                           u, v, c->d_counters, env_int("PTGPU_RAYCAST_REFILL", 32));
-    } else {
-        dim3 grid((unsigned)((n + RC_BLOCK - 1) / RC_BLOCK));
-        if (impl == 1)
-            hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, NLDS, OVF>), grid, block, 0, st, trav, o, d, n, id, t, u, v, c->d_counters);
-        else if constexpr (NLDS == RC_NLDS)
-            hipLaunchKernelGGL((k_raycast<ANYHIT, ALPHA, COUNT, OVF>), grid, block, 0, st, trav, o, d, n, id, t, u, v, c->d_counters);
-        else
-            return fail(PTGPU_E_UNSUPPORTED, "while-while kernel is only built with %d LDS stack entries", RC_NLDS);
+    long long want = (n + RC_CHUNK - 1) / RC_CHUNK;  // no more waves than chunks
+    long long blocks = (want + (RC_BLOCK / 64) - 1) / (RC_BLOCK / 64);
+    // a small multiple of the blocks resident at once (LDS-limited): long-lived waves, dispatcher-level balancing
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>, RC_BLOCK, 0) != hipSuccess || v < 1) v = 1;
+        per_cu = v;
     }
+    long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_RAYCAST_OVERSUB", 1);
+    if (blocks > resident) blocks = resident;
+    if (OVF) {
+        int rc = ensure_stack_overflow(c, (size_t)blocks * (RC_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
+        if (rc != PTGPU_OK) return rc;
+    }
+    hipLaunchKernelGGL((k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(RC_BLOCK), 0, c->stream, trav, o, d, n, id, t,
+                       u, v, c->d_counters, env_int("PTGPU_RAYCAST_REFILL", 32), c->d_stack_ovf);
     return PTGPU_OK;
 }
 
 template <bool ANYHIT, bool ALPHA, bool COUNT>
 static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
-    RcConfig cfg = rc_config();
+    ptgpu_context* c = s->ctx;
+    ptd::TravScene trav = s->trav;
+    trav.alpha_on = ALPHA ? 1 : 0;
     // stack occupancy <= depth - 1 (one far sibling per ancestor level); the counting variant pushes every far child as well
     const int need = s->depth - 1;
-    if constexpr (!ALPHA && !COUNT) {  // tuning variants are only built for the plain kernels
-        if (cfg.nlds == 8) return need > 8 ? launch_rc_impl<ANYHIT, ALPHA, COUNT, 8, true>(s, cfg.impl, o, d, n, id, t, u, v)
-                                           : launch_rc_impl<ANYHIT, ALPHA, COUNT, 8, false>(s, cfg.impl, o, d, n, id, t, u, v);
-        if (cfg.nlds == 24) return need > 24 ? launch_rc_impl<ANYHIT, ALPHA, COUNT, 24, true>(s, cfg.impl, o, d, n, id, t, u, v)
-                                             : launch_rc_impl<ANYHIT, ALPHA, COUNT, 24, false>(s, cfg.impl, o, d, n, id, t, u, v);
+    const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", 24);
+    dim3 grid((unsigned)((n + RC_BLOCK - 1) / RC_BLOCK)), block(RC_BLOCK);
+    if constexpr (COUNT || ALPHA) {  // rare variants: one configuration that is valid for every depth
+        return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
+    } else {
+        if (need > 24 || (need > 16 && nlds == 16)) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
+        if (impl == 2) return nlds == 16 ? launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, false>(s, trav, o, d, n, id, t, u, v)
+                                         : launch_rc_persist<ANYHIT, ALPHA, COUNT, 24, false>(s, trav, o, d, n, id, t, u, v);
+        if (nlds == 16) hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 16>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters);
+        else hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 24>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters);
+        return PTGPU_OK;
     }
-    return need > RC_NLDS ? launch_rc_impl<ANYHIT, ALPHA, COUNT, RC_NLDS, true>(s, cfg.impl, o, d, n, id, t, u, v)
-                          : launch_rc_impl<ANYHIT, ALPHA, COUNT, RC_NLDS, false>(s, cfg.impl, o, d, n, id, t, u, v);
 }
 
 extern "C" int ptgpu_raycast_batch_dev(ptgpu_scene* s, int use_alpha, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
@@ -692,15 +683,20 @@ extern "C" int ptgpu_gen_shadow_dev(ptgpu_scene* s, const ptgpu_light* light, in
 //   k_resolve          updatePicture (:855-871)
 // ------------------------------------------------------------------------------------------------
 constexpr int PT_BLOCK = 256;
-constexpr int PT_NLDS = 24;
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument): <= 128 VGPRs.
+                        // Measured on the configs[2] frame: 4 waves + 16 LDS stack entries 32.0 ms vs 3 waves + 24 entries 34.6 ms per 16 spp
+#endif
 
-template <bool COUNT, bool OVF>
-__global__ __launch_bounds__(PT_BLOCK) void k_integrate(ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
+template <bool COUNT, int NLDS, bool OVF>
+__global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void k_integrate(ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
                                                         const ptgpu_light* __restrict__ lights, ptd::PassDesc pd, float4* __restrict__ rad,
-                                                        unsigned long long* counters, int service_threshold) {
-    __shared__ uint2 lds_stack[PT_BLOCK / 64][PT_NLDS][64];
+                                                        unsigned long long* counters, int service_threshold, uint2* stack_ovf) {
+    __shared__ uint2 lds_stack[PT_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    ptd::integrate<COUNT, PT_NLDS, OVF, PT_BLOCK>(TS, SS, prm, cam, lights, pd, rad, counters, &lds_stack[wave][0][lane], service_threshold);
+    const size_t wave_id = (size_t)blockIdx.x * (PT_BLOCK / 64) + wave;
+    ptd::integrate<COUNT, NLDS, OVF, PT_BLOCK>(TS, SS, prm, cam, lights, pd, rad, counters, &lds_stack[wave][0][lane],
+                                               OVF ? stack_ovf + wave_id * (64 - NLDS) * 64 + lane : nullptr, service_threshold);
 }
 
 __device__ __forceinline__ void block_rect(const ptgpu_params& prm, const ptd::PassDesc& pd, int jj, int& bx, int& by, int& bw, int& bh) {
@@ -831,22 +827,27 @@ static int check_params(const ptgpu_params* p) {
     return PTGPU_OK;
 }
 
-template <bool COUNT, bool OVF>
-static void launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const ptd::ShadeScene& ss, const ptgpu_params* prm, const ptgpu_camera* cam,
-                             const ptd::PassDesc& pd) {
+template <bool COUNT, int NLDS, bool OVF>
+static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const ptd::ShadeScene& ss, const ptgpu_params* prm, const ptgpu_camera* cam,
+                            const ptd::PassDesc& pd) {
     ptgpu_context* c = s->ctx;
     static int per_cu = 0;
     if (per_cu == 0) {
         int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_integrate<COUNT, OVF>, PT_BLOCK, 0) != hipSuccess || v < 1) v = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_integrate<COUNT, NLDS, OVF>, PT_BLOCK, 0) != hipSuccess || v < 1) v = 1;
         per_cu = v;
     }
     const long long total = (long long)pd.num_blocks * pd.samples_per_block;
     long long blocks = (total + PT_BLOCK - 1) / PT_BLOCK;
     const long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_PT_OVERSUB", 1);
     if (blocks > resident) blocks = resident;
-    hipLaunchKernelGGL((k_integrate<COUNT, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
-                       c->d_counters, env_int("PTGPU_PT_SERVICE", 32));
+    if (OVF) {
+        int rc = ensure_stack_overflow(c, (size_t)blocks * (PT_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
+        if (rc != PTGPU_OK) return rc;
+    }
+    hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
+                       c->d_counters, env_int("PTGPU_PT_SERVICE", 40), c->d_stack_ovf);
+    return PTGPU_OK;
 }
 
 extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, const ptgpu_camera* cam, const ptgpu_light* lights, int32_t num_lights,
@@ -888,15 +889,18 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     trav.alpha_on = (prm->use_alpha && s->has_alpha) ? 1 : 0;
     ptd::ShadeScene ss;
     ss.pos = s->d_pos; ss.nrm = s->d_nrm; ss.uv = s->d_uv; ss.materials = s->d_materials; ss.textures = s->d_textures;
-    const bool ovf = (s->depth - 1) > PT_NLDS;
+    const int stack_need = s->depth - 1, nlds = env_int("PTGPU_PT_NLDS", 16);
     for (int j0 = 0; j0 < count; j0 += (int)batch_blocks) {
         ptd::PassDesc pd;
         pd.block_begin = block_begin; pd.block_stride = block_stride; pd.j0 = j0;
         pd.num_blocks = (count - j0 < batch_blocks) ? count - j0 : (int)batch_blocks;
         pd.blocks_x = blocks_x; pd.samples_per_block = (int32_t)spb; pd.num_lights = num_lights;
         pd.inv_prob = 1.0f / prm->termination_prob;
-        if (c->count) { if (ovf) launch_integrate<true, true>(s, trav, ss, prm, cam, pd); else launch_integrate<true, false>(s, trav, ss, prm, cam, pd); }
-        else { if (ovf) launch_integrate<false, true>(s, trav, ss, prm, cam, pd); else launch_integrate<false, false>(s, trav, ss, prm, cam, pd); }
+        if (c->count) rc = launch_integrate<true, 16, true>(s, trav, ss, prm, cam, pd);
+        else if (stack_need > 24 || (stack_need > 16 && nlds == 16)) rc = launch_integrate<false, 16, true>(s, trav, ss, prm, cam, pd);
+        else if (nlds == 16) rc = launch_integrate<false, 16, false>(s, trav, ss, prm, cam, pd);
+        else rc = launch_integrate<false, 24, false>(s, trav, ss, prm, cam, pd);
+        if (rc != PTGPU_OK) return rc;
         if (prm->sobol_block) {
             HIP_TRY(hipMemsetAsync(c->d_counters + 3, 0, sizeof(unsigned long long), c->stream));
             hipLaunchKernelGGL(k_accum_sobol, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum, c->d_spill, c->d_counters);

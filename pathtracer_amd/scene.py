@@ -156,7 +156,121 @@ def grid_scene(nx=8, ny=8, seed=1, jitter=0.3):
 
 
 def flat_normals(pos):
+    pos = np.asarray(pos, np.float64)  # float64: squared edge lengths of very large triangles overflow float32
     e1, e2 = pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]
     n = np.cross(e1, e2)
-    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-20)
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-300)
     return np.repeat(n[:, None, :], 3, axis=1).astype(np.float32)
+
+
+# ---- procedural stand-in scenes for BASELINE configs[3] and [4] (Sponza is not in the reference checkout) ----
+def _grid_patch(p00, du, dv, nu, nv, disp=None):
+    """Tessellated parallelogram p00 + s*du + t*dv, (nu x nv) quads -> triangles [2*nu*nv,3,3], uv [.,3,2]."""
+    s, t = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    P = p00[None, None, :] + s[..., None] * du[None, None, :] + t[..., None] * dv[None, None, :]
+    if disp is not None:
+        P = P + disp(s, t)
+    UV = np.stack([s * 4.0, t * 4.0], -1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    ua, ub, uc, ud = UV[:-1, :-1], UV[1:, :-1], UV[1:, 1:], UV[:-1, 1:]
+    tri = np.concatenate([np.stack([a, b, c], -2).reshape(-1, 3, 3), np.stack([a, c, d], -2).reshape(-1, 3, 3)])
+    uv = np.concatenate([np.stack([ua, ub, uc], -2).reshape(-1, 3, 2), np.stack([ua, uc, ud], -2).reshape(-1, 3, 2)])
+    return tri, uv
+
+
+def _smooth_normals_flat(pos):
+    return flat_normals(pos.astype(np.float32))
+
+
+def atrium_scene(target_tris=262144, seed=7):
+    """Procedural "atrium" standing in for Crytek Sponza (BASELINE configs[3]): a long hall with a displaced
+    stone floor, side walls, two rows of fluted columns, arches between them and hanging sinusoidal curtains.  Deterministic.
+    Returns dict(pos, nrm, uv, mat_id, materials) with ~target_tris triangles and 4 materials."""
+    rng = np.random.RandomState(seed)
+    k = max(1, int(round(np.sqrt(target_tris / 262144.0) * 16)))  # tessellation unit
+    parts, uvs, mats = [], [], []
+
+    def add(tri, uv, m):
+        parts.append(tri); uvs.append(uv); mats.append(np.full(tri.shape[0], m, np.int32))
+
+    bump = lambda amp: (lambda s, t: np.stack([np.zeros_like(s), amp * np.sin(37 * s) * np.cos(29 * t), np.zeros_like(s)], -1))  # noqa: E731
+    L, Wd, Hh = 12.0, 5.0, 6.0
+    add(*_grid_patch(np.array([-L / 2, 0, -Wd / 2]), np.array([L, 0, 0.0]), np.array([0, 0, Wd]), 12 * k, 5 * k, bump(0.01)), 0)   # floor
+    wall = lambda s, t: np.stack([np.zeros_like(s), np.zeros_like(s), 0.02 * np.sin(23 * s) * np.sin(31 * t)], -1)  # noqa: E731
+    add(*_grid_patch(np.array([-L / 2, 0, -Wd / 2]), np.array([L, 0, 0.0]), np.array([0, Hh, 0.0]), 10 * k, 5 * k, wall), 1)
+    add(*_grid_patch(np.array([L / 2, 0, Wd / 2]), np.array([-L, 0, 0.0]), np.array([0, Hh, 0.0]), 10 * k, 5 * k, wall), 1)
+    add(*_grid_patch(np.array([-L / 2, 0, Wd / 2]), np.array([0, 0, -Wd]), np.array([0, Hh, 0.0]), 4 * k, 5 * k, wall), 1)         # back wall
+    ncol = 6
+    for side in (-1.0, 1.0):
+        for ci in range(ncol):
+            cx, cz, r = -L / 2 + (ci + 0.5) * L / ncol, side * Wd * 0.28, 0.22
+            nu, nv = 3 * k, 4 * k
+            th, hh = np.meshgrid(np.linspace(0, 2 * np.pi, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+            rr = r * (1.0 + 0.06 * np.cos(12 * th)) * (1.0 + 0.15 * (hh - 0.5) ** 2)
+            P = np.stack([cx + rr * np.cos(th), hh * 3.6, cz + rr * np.sin(th)], -1)
+            UV = np.stack([th / (2 * np.pi) * 2, hh * 4], -1)
+            a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+            ua, ub, uc, ud = UV[:-1, :-1], UV[1:, :-1], UV[1:, 1:], UV[:-1, 1:]
+            add(np.concatenate([np.stack([a, c, b], -2).reshape(-1, 3, 3), np.stack([a, d, c], -2).reshape(-1, 3, 3)]),
+                np.concatenate([np.stack([ua, uc, ub], -2).reshape(-1, 3, 2), np.stack([ua, ud, uc], -2).reshape(-1, 3, 2)]), 2)
+            if ci + 1 < ncol:  # arch to the next column: half torus
+                nu2, nv2 = 3 * k, 2 * k
+                ph, ps = np.meshgrid(np.linspace(0, np.pi, nu2 + 1), np.linspace(0, 2 * np.pi, nv2 + 1), indexing="ij")
+                R0, r0 = L / ncol / 2, 0.12
+                ax = cx + R0 - (R0 + r0 * np.cos(ps)) * np.cos(ph)
+                ay = 3.6 + (R0 + r0 * np.cos(ps)) * np.sin(ph) * 0.8
+                az = cz + r0 * np.sin(ps)
+                P = np.stack([ax, ay, az], -1)
+                UV = np.stack([ph / np.pi * 3, ps / (2 * np.pi)], -1)
+                a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+                ua, ub, uc, ud = UV[:-1, :-1], UV[1:, :-1], UV[1:, 1:], UV[:-1, 1:]
+                add(np.concatenate([np.stack([a, b, c], -2).reshape(-1, 3, 3), np.stack([a, c, d], -2).reshape(-1, 3, 3)]),
+                    np.concatenate([np.stack([ua, ub, uc], -2).reshape(-1, 3, 2), np.stack([ua, uc, ud], -2).reshape(-1, 3, 2)]), 2)
+    for ci in range(5):  # curtains
+        cx = -L / 2 + (ci + 1) * L / 6 + rng.uniform(-0.2, 0.2)
+        ph0 = rng.uniform(0, 6.28)
+        fold = lambda s, t, ph0=ph0: np.stack([np.zeros_like(s), np.zeros_like(s), 0.12 * np.sin(18 * s + ph0) * (0.3 + t)], -1)  # noqa: E731
+        add(*_grid_patch(np.array([cx - 0.7, 4.8, 0.0]), np.array([1.4, 0, 0.0]), np.array([0, -2.6, 0.0]), 5 * k, 5 * k, fold), 3)
+    pos = np.concatenate(parts).astype(np.float32)
+    uv = np.concatenate(uvs).astype(np.float32)
+    mat_id = np.concatenate(mats)
+    materials = [make_material(diffuse=(0.55, 0.52, 0.48, 1), specular=(0.05, 0.05, 0.05), glossiness=10.0),
+                 make_material(diffuse=(0.70, 0.66, 0.58, 1), specular=(0.02, 0.02, 0.02), glossiness=5.0),
+                 make_material(diffuse=(0.75, 0.73, 0.70, 1), specular=(0.15, 0.15, 0.15), glossiness=50.0),
+                 make_material(diffuse=(0.65, 0.12, 0.10, 1), specular=(0.05, 0.05, 0.05), glossiness=20.0)]
+    return dict(pos=pos, nrm=_smooth_normals_flat(pos), uv=uv, mat_id=mat_id, materials=materials)
+
+
+def atrium_view(width, height):
+    """Camera + two area lights for atrium_scene (looking down the hall)."""
+    cam = make_camera(eye=(-5.2, 1.7, 0.1), forward=(1.0, 0.08, -0.02), up=(0, 1, 0), fov_deg=65.0, near=0.01, far=30.0, width=width, height=height)
+    lights = [make_light(position=(0.0, 5.6, 0.0), col0=(1, 0, 0), col1=(0, 0, -1), col2=(0, 1, 0), size=(2.5, 0.8), E=(30, 28, 25)),
+              make_light(position=(3.5, 4.5, 0.0), col0=(1, 0, 0), col1=(0, 0, -1), col2=(0, 1, 0), size=(0.5, 0.5), E=(60, 50, 40), intensity=1.5)]
+    return cam, lights
+
+
+def tetra_cloud_scene(num_tris=10_000_000, seed=11):
+    """BVH-bandwidth stress scene (BASELINE configs[4]): a jittered grid of small tetrahedra in the unit box
+    [-0.5,0.5]^3 plus a floor.  num_tris is rounded down to a multiple of 4.  Returns dict(pos, nrm, uv, mat_id, materials)."""
+    n_tet = num_tris // 4
+    g = int(np.ceil(n_tet ** (1.0 / 3.0)))
+    rng = np.random.RandomState(seed)
+    idx = np.arange(n_tet)
+    cell = np.stack([idx % g, (idx // g) % g, idx // (g * g)], 1).astype(np.float32)
+    c = (cell + 0.5 + rng.uniform(-0.35, 0.35, (n_tet, 3)).astype(np.float32)) / g - 0.5
+    r = 0.45 / g
+    v = c[:, None, :] + rng.uniform(-1, 1, (n_tet, 4, 3)).astype(np.float32) * r
+    faces = np.array([[0, 1, 2], [0, 2, 3], [0, 3, 1], [1, 3, 2]])
+    pos = v[:, faces, :].reshape(-1, 3, 3).astype(np.float32)
+    uv = np.tile(np.array([[0, 0], [1, 0], [0, 1]], np.float32), (pos.shape[0], 1, 1))
+    mat_id = (np.arange(pos.shape[0]) // 4 % 3).astype(np.int32)
+    materials = [make_material(diffuse=(0.8, 0.3, 0.25, 1), specular=(0.1, 0.1, 0.1), glossiness=30.0),
+                 make_material(diffuse=(0.3, 0.75, 0.35, 1), specular=(0.1, 0.1, 0.1), glossiness=30.0),
+                 make_material(diffuse=(0.3, 0.4, 0.85, 1), specular=(0.1, 0.1, 0.1), glossiness=30.0)]
+    return dict(pos=pos, nrm=flat_normals(pos), uv=uv, mat_id=mat_id, materials=materials)
+
+
+def tetra_cloud_view(width, height):
+    cam = make_camera(eye=(0.0, 0.15, 1.25), forward=(0.0, -0.1, -1.0), up=(0, 1, 0), fov_deg=50.0, near=0.01, far=4.0, width=width, height=height)
+    lights = [make_light(position=(0.0, 0.95, 0.3), col0=(1, 0, 0), col1=(0, 0, -1), col2=(0, 1, 0), size=(0.4, 0.4), E=(40, 40, 40))]
+    return cam, lights
