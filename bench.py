@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--pt-passes", type=int, default=3, help="timed passes of the path-trace leg (0 = skip the leg)")
     ap.add_argument("--pt-spp", type=int, default=PT_SPP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the measured configuration); gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,14 +70,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible: one rank per GPU" % (local_rank, ndev))
+    dev_index = local_rank % max(ndev, 1)  # gloo rehearsal: ranks may share a GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the scalar reductions live
 
     sd, bvh_stats = build_head_scene()
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
     # a real (non-null) stream shared by the library's launches and torch's events: torch.cuda.Event only sees the stream
     # it is recorded on, and a NULL handle would make the library fall back to its own stream
     stream = torch.cuda.Stream(dev)
@@ -132,8 +142,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    total_rays = torch.tensor([rays_per_step * args.steps], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    total_rays = torch.tensor([rays_per_step * args.steps], dtype=torch.int64, device=red_dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_rays, op=dist.ReduceOp.SUM)
@@ -143,7 +153,7 @@ def main():
     anyhit_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
     gscene.close()
 
-    pt = path_trace_leg(args, ctx, stream, dev, rank, world) if args.pt_passes > 0 else None
+    pt = path_trace_leg(args, ctx, stream, dev, red_dev, rank, world) if args.pt_passes > 0 else None
 
     if rank == 0:
         achieved = bytes_primary / (closest_ms * 1e-3) / 1e9
@@ -179,13 +189,13 @@ def main():
         dist.destroy_process_group()
 
 
-def path_trace_leg(args, ctx, stream, dev, rank, world):
+def path_trace_leg(args, ctx, stream, dev, red_dev, rank, world):
     """configs[2]: full path trace of the 1080p head frame; blocks dealt round-robin over ranks, tiles gathered over RCCL."""
     sd, _ = build_head_scene(textured=True)
     gscene = capi.Scene(ctx, sd)
     cam, lights = scene.make_camera(width=W, height=H), [scene.make_light()]
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device=dev)
-    tg = multigpu.TileGather(W, H, rank, world, dev)
+    tg = multigpu.TileGather(W, H, rank, world, dev, stage_on_cpu=(args.backend == "gloo"))
 
     def params(seed):
         return scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=args.pt_spp, sobol_block=False, bilinear=True, normal_mapped=True,
@@ -222,8 +232,8 @@ def path_trace_leg(args, ctx, stream, dev, rank, world):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    rays = torch.tensor([ctx.counters()["rays"]], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([ctx.counters()["rays"]], dtype=torch.int64, device=red_dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -235,7 +245,7 @@ def path_trace_leg(args, ctx, stream, dev, rank, world):
     achieved = bytes_per_ray * (local_rays / args.pt_passes) / (render_ms * 1e-3) / 1e9
     return {"workload": "head.obj full path trace %dx%d, %d spp, Gaussian AA, bilinear textures + normal maps (procedural stand-in maps), "
                         "RR after 1 bounce p=0.2 (BASELINE configs[2])" % (W, H, args.pt_spp),
-            "passes": args.pt_passes, "scaling": "strong" if world > 1 else "n/a", "tile_gather": "RCCL all_gather of packed 32x32-block tiles" if world > 1 else "none",
+            "passes": args.pt_passes, "scaling": "strong" if world > 1 else "n/a", "tile_gather": ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)") + " all_gather of packed 32x32-block tiles" if world > 1 else "none",
             "samples_per_s": samples / elapsed, "Mrays_per_s": rays / elapsed / 1e6, "rays_per_sample": rays / samples,
             "ms_per_pass": elapsed / args.pt_passes * 1e3, "render_ms_per_pass_rank0": render_ms,
             "per_ray": {"nodes": c["node_visits"] / max(c["rays"], 1), "tris": c["tri_tests"] / max(c["rays"], 1), "bytes": bytes_per_ray},

@@ -39,8 +39,11 @@ def rank_pixel_index(rank, world, width, height):
 class TileGather:
     """Precomputed pack / unpack indices for one image size and world size."""
 
-    def __init__(self, width, height, rank, world, device):
+    def __init__(self, width, height, rank, world, device, stage_on_cpu=False):
+        """stage_on_cpu: run the collective on host copies of the packed tiles (gloo rehearsals of a GPU job; RCCL takes the
+        device buffers directly)."""
         self.width, self.height, self.rank, self.world = width, height, rank, world
+        self.stage_on_cpu = stage_on_cpu and torch.device(device).type != "cpu"
         idx = [rank_pixel_index(r, world, width, height) for r in range(world)]
         self.counts = [int(i.size) for i in idx]
         self.pad = max(self.counts) if self.counts else 0
@@ -56,7 +59,12 @@ class TileGather:
             return accum
         mine = self.index[self.rank]
         self.packed[: mine.numel()] = img[mine]
-        dist.all_gather_into_tensor(self.gathered.view(-1), self.packed.view(-1))
+        if self.stage_on_cpu:
+            host = torch.empty(self.gathered.shape, dtype=torch.float32)
+            dist.all_gather_into_tensor(host.view(-1), self.packed.cpu().view(-1))
+            self.gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.packed.view(-1))
         for r in range(self.world):
             if r != self.rank:
                 img[self.index[r]] = self.gathered[r, : self.counts[r]]
