@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstring>
 #include <future>
+#include <cstdlib>
 #include <thread>
 
 namespace FW {
@@ -29,7 +30,12 @@ bool FlatNode::intersect(const Vec3f& orig, const Vec3f& invDir, const int sign[
 
 BVH::BVH(std::vector<RTTriangle>* triangles, bool sah, int numThreads) : m_sahEnabled(sah), m_triangles(triangles) {
     const size_t n = triangles->size();
-    m_numThreads = numThreads > 0 ? numThreads : (int)std::max(1u, std::thread::hardware_concurrency());
+    // default: the machine's cores, but never more than PT_HOST_THREADS / OMP_NUM_THREADS (or 16): hardware_concurrency() reports the
+    // whole host on shared GPU boxes, many times this process's share
+    int cap = 16;
+    for (const char* var : {"PT_HOST_THREADS", "OMP_NUM_THREADS"})
+        if (const char* e = std::getenv(var)) { int v = std::atoi(e); if (v > 0) { cap = v; break; } }
+    m_numThreads = numThreads > 0 ? numThreads : std::min(cap, (int)std::max(1u, std::thread::hardware_concurrency()));
     list.resize(n);
     m_centroid.resize(n); m_min.resize(n); m_max.resize(n);
     for (size_t i = 0; i < n; ++i) {
