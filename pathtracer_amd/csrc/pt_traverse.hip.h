@@ -73,14 +73,38 @@ __device__ __forceinline__ void slab(float nx, float ny, float nz, float fx, flo
     tentry = tmin;
 }
 
-template <int NLDS, bool OVF>
+// The same test for rays whose arithmetic cannot produce a NaN (every 1/dir component finite and non-zero, origin finite; box
+// planes are validated NaN-free at scene creation): with near = min and far = max of the two plane distances per axis, the
+// reference's compare chain reduces to  max3(near) <= min3(far)  (its misses are exactly "some near_i > some far_j", i != j, and
+// near_i <= far_i always), its tmax is min3(far) and its tmin is max3(near) -- the same floats, because min/max return one of
+// their operands.  Rays with a zero, infinite or NaN direction component keep slab(): there 0 * inf = NaN decides the outcome
+// through comparisons that are false, which min/max would not reproduce.
+__device__ __forceinline__ void slab_fast(float lx, float ly, float lz, float hx, float hy, float hz, F3 o, F3 inv, bool& ok, float& tentry) {
+    const float ax = (lx - o.x) * inv.x, bx = (hx - o.x) * inv.x;
+    const float ay = (ly - o.y) * inv.y, by = (hy - o.y) * inv.y;
+    const float az = (lz - o.z) * inv.z, bz = (hz - o.z) * inv.z;
+    const float te = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    ok = (te <= tx) && (tx > 0.0f);
+    tentry = te;
+}
+
+// What happens when a lane needs more than NLDS entries:
+//   OVF    entries NLDS.. live in a per-wave region of global memory (persistent kernels: a bounded set of waves);
+//   DEFER  nothing is written; `full` is raised and the traverser gives the ray up, for the caller to re-trace it with an
+//          OVF kernel (one-ray-per-lane grids, which have no bounded set of waves to own overflow regions);
+//   neither: the host has proved from the tree depth that NLDS entries suffice.
+template <int NLDS, bool OVF, bool DEFER = false>
 struct LaneStack {
     uint2* lds;  // this lane's slot of entry 0; entry e is lds[e * 64]
     uint2* gl;   // OVF only: this lane's slot of overflow entry 0 in global memory; entry e is gl[e * 64]
     int sp;
+    bool full;   // DEFER only
     __device__ __forceinline__ void push(int ref, float tentry) {
         uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tentry));
-        if (!OVF || sp < NLDS) lds[sp * 64] = e;
+        if (DEFER) {
+            if (sp < NLDS) lds[sp * 64] = e; else full = true;
+        } else if (!OVF || sp < NLDS) lds[sp * 64] = e;
         else gl[(sp - NLDS) * 64] = e;
         ++sp;
     }
@@ -93,139 +117,18 @@ struct LaneStack {
 // bytes of global overflow space one wave needs (entries NLDS..63 for 64 lanes)
 template <int NLDS> constexpr size_t stack_overflow_bytes_per_wave() { return (size_t)(64 - NLDS) * 64 * sizeof(uint2); }
 
-// ANYHIT: occlusion flag of raycast().  ALPHA: alpha-texture cutout enabled and present in the scene.
+// ALPHA: alpha-texture cutout compiled in (and enabled by TravScene::alpha_on).
 // COUNT: also count the reference's node visits / triangle tests (far children are then always pushed so
 // that the counts equal the CPU traversal's exactly; results are unchanged).
-template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
-__device__ __forceinline__ HitRec traverse(const TravScene& S, F3 o, F3 d, uint2* lds_lane, uint2* gl_lane, uint32_t& n_nodes, uint32_t& n_tris) {
-    HitRec best;
-    best.id = -1; best.t = 3.402823466e+38f; best.u = 0.0f; best.v = 0.0f;
-    if (S.list_size <= 0) return best;
-
-    float tmin = 1.0f, umin = 0.0f, vmin = 0.0f;
-    int pmin = -1;
-    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-    const uint32_t signbits = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
-
-    LaneStack<NLDS, OVF> st;
-    st.lds = lds_lane;
-    st.gl = gl_lane;
-    st.sp = 0;
-
-    int cur = S.root_ref;
-    bool alive;
-    {
-        bool ok; float te;
-        slab(sx ? S.root_bmax[0] : S.root_bmin[0], sy ? S.root_bmax[1] : S.root_bmin[1], sz ? S.root_bmax[2] : S.root_bmin[2],
-             sx ? S.root_bmin[0] : S.root_bmax[0], sy ? S.root_bmin[1] : S.root_bmax[1], sz ? S.root_bmin[2] : S.root_bmax[2],
-             o, inv, ok, te);
-        alive = ok && (te < tmin);
-        if (COUNT) n_nodes += 1;
-    }
-
-    while (alive) {
-        // ---- interior nodes: descend until this lane holds a leaf (or runs out of work) ----
-        while (alive && cur >= 0) {
-            const float4* np = S.inner + (size_t)cur * 4;
-            float4 a = ldg4(np), b = ldg4(np + 1), c = ldg4(np + 2), m = ldg4(np + 3);
-            // left box: min (a.x a.y a.z) max (a.w b.x b.y); right box: min (b.z b.w c.x) max (c.y c.z c.w)
-            bool okL, okR; float teL, teR;
-            slab(sx ? a.w : a.x, sy ? b.x : a.y, sz ? b.y : a.z, sx ? a.x : a.w, sy ? a.y : b.x, sz ? a.z : b.y, o, inv, okL, teL);
-            slab(sx ? c.y : b.z, sy ? c.z : b.w, sz ? c.w : c.x, sx ? b.z : c.y, sy ? b.w : c.z, sz ? c.x : c.w, o, inv, okR, teR);
-            int refL = __float_as_int(m.x), refR = __float_as_int(m.y);
-            bool rightFirst = ((signbits >> __float_as_int(m.z)) & 1u) != 0u;  // sign[node.axis]
-            int refN = rightFirst ? refR : refL, refF = rightFirst ? refL : refR;
-            bool okN = rightFirst ? okR : okL, okF = rightFirst ? okL : okR;
-            float teN = rightFirst ? teR : teL, teF = rightFirst ? teL : teR;
-            bool passN = okN && (teN < tmin);
-            bool passF = okF && (teF < tmin);
-            if (COUNT) {
-                n_nodes += 1;  // the near child is visited now; the far child when it is popped
-                st.push(refF, passF ? teF : __uint_as_float(0x7f800000u));
-                passF = false;
-            }
-            if (passN) {
-                if (passF) st.push(refF, teF);
-                cur = refN;
-            } else if (passF) {
-                cur = refF;
-            } else {
-                alive = false;
-                while (st.sp > 0) {
-                    uint2 e = st.pop();
-                    if (COUNT) n_nodes += 1;
-                    if (__uint_as_float(e.y) < tmin) { cur = (int)e.x; alive = true; break; }
-                }
-            }
-        }
-        if (!alive) break;
-
-        // ---- leaf: scan its triangle records ----
-        int pos = ~cur;
-        for (;;) {
-            const float4* tp = S.tris + (size_t)pos * 4;
-            float4 r0 = ldg4(tp), r1 = ldg4(tp + 1), r2 = ldg4(tp + 2), r3 = ldg4(tp + 3);
-            if (COUNT) n_tris += 1;
-            float ox = (r0.x * o.x + r0.y * o.y + r0.z * o.z) + r0.w;
-            float oy = (r1.x * o.x + r1.y * o.y + r1.z * o.z) + r1.w;
-            float oz = (r2.x * o.x + r2.y * o.y + r2.z * o.z) + r2.w;
-            float dx = r0.x * d.x + r0.y * d.y + r0.z * d.z;
-            float dy = r1.x * d.x + r1.y * d.y + r1.z * d.z;
-            float dz = r2.x * d.x + r2.y * d.y + r2.z * d.z;
-            float t = -oz / dz;
-            float u = ox + dx * t;
-            float v = oy + dy * t;
-            if (u > 0.0f && v > 0.0f && u + v < 1.0f) {
-                bool keep = true;
-                if (ALPHA) {
-                    int atex = __float_as_int(r3.z);
-                    if (S.alpha_on && atex >= 0) {  // RayTracer.cpp:204-225: green channel of the alpha map < 0.5 => cut out
-                        const float* tc = S.uv + (size_t)__float_as_int(r3.x) * 6;
-                        F2 uv = (1 - u - v) * ld2(tc) + u * ld2(tc + 2) + v * ld2(tc + 4);
-                        DevTexture tx = S.textures[atex];
-                        int x = (int)((uv.x - floorf(uv.x)) * tx.width);
-                        int y = (int)((uv.y - floorf(uv.y)) * tx.height);
-                        x = x < 0 ? 0 : (x > tx.width - 1 ? tx.width - 1 : x);
-                        y = y < 0 ? 0 : (y > tx.height - 1 ? tx.height - 1 : y);
-                        float alpha = (float)tx.rgba[((size_t)y * tx.width + x) * 4 + 1] / 255.0f;
-                        keep = !(alpha < 0.5f);
-                    }
-                }
-                if (keep && t > 0.0f && t < tmin) {
-                    pmin = pos; tmin = t; umin = u; vmin = v;
-                    if (ANYHIT) { alive = false; break; }
-                }
-            }
-            if (__float_as_int(r3.y) == 0) break;
-            ++pos;
-        }
-        if (ANYHIT && !alive) break;
-
-        // ---- next node from the stack ----
-        alive = false;
-        while (st.sp > 0) {
-            uint2 e = st.pop();
-            if (COUNT) n_nodes += 1;
-            if (__uint_as_float(e.y) < tmin) { cur = (int)e.x; alive = true; break; }
-        }
-    }
-    if (pmin >= 0) {
-        best.id = __float_as_int(S.tris[(size_t)pmin * 4 + 3].x);
-        best.t = tmin; best.u = umin; best.v = vmin;
-    }
-    return best;
-}
-
 
 // ------------------------------------------------------------------------------------------------------------------
-// Step-wise traverser: the same traversal as traverse() above, cut into single steps so that a wave never waits on
+// Step-wise traverser: the reference's traversal cut into single steps so that a wave never waits on
 // its slowest lane inside a phase.  Node records and triangle records are both 64 B, so ONE 4 x dwordx4 fetch per step
 // serves every lane whatever it is doing (visiting an interior node or testing one triangle); the two arithmetic
 // bodies then run under their own exec masks.  A lane that finishes can be handed a new ray by its kernel between two
-// steps (persistent waves with refill).  Hit records are identical to traverse(): same tests, same order.
+// steps (persistent waves with refill).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool ALPHA, bool COUNT, int NLDS, bool OVF>
+template <bool ALPHA, bool COUNT, int NLDS, bool OVF, bool DEFER = false>
 struct Trav {
     F3 o, d, inv;
     uint32_t signbits;
@@ -233,12 +136,15 @@ struct Trav {
     int pmin;
     int cur;
     bool alive, anyhit;
-    LaneStack<NLDS, OVF> st;
+    bool fast;  // no NaN can arise in this ray's slab tests: slab_fast applies
+    LaneStack<NLDS, OVF, DEFER> st;
     uint32_t n_nodes, n_tris;
 
     __device__ __forceinline__ void reset_counts() { n_nodes = 0; n_tris = 0; }
 
-    __device__ __forceinline__ void attach(uint2* lds_lane, uint2* gl_lane) { st.lds = lds_lane; st.gl = gl_lane; st.sp = 0; }
+    __device__ __forceinline__ void attach(uint2* lds_lane, uint2* gl_lane) { st.lds = lds_lane; st.gl = gl_lane; st.sp = 0; st.full = false; }
+    // DEFER: the ray ran out of LDS stack and was given up (alive is false, no result): re-trace it with an OVF kernel
+    __device__ __forceinline__ bool deferred() const { return DEFER && st.full; }
 
     __device__ __forceinline__ void begin(const TravScene& S, F3 o_, F3 d_, bool anyhit_) {
         o = o_; d = d_; anyhit = anyhit_;
@@ -246,7 +152,12 @@ struct Trav {
         inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
         signbits = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
+        {   // x * 0 == 0 exactly for finite x only; != 0 excludes 1/inf
+            const float z = inv.x * 0.0f + inv.y * 0.0f + inv.z * 0.0f + o.x * 0.0f + o.y * 0.0f + o.z * 0.0f;
+            fast = (z == 0.0f) && inv.x != 0.0f && inv.y != 0.0f && inv.z != 0.0f;
+        }
         st.sp = 0;
+        st.full = false;
         cur = S.root_ref;
         alive = false;
         if (S.list_size > 0) {
@@ -275,8 +186,13 @@ struct Trav {
         const bool sx = (signbits & 1u) != 0u, sy = (signbits & 2u) != 0u, sz = (signbits & 4u) != 0u;
         if (cur >= 0) {
             bool okL, okR; float teL, teR;
-            slab(sx ? a.w : a.x, sy ? b.x : a.y, sz ? b.y : a.z, sx ? a.x : a.w, sy ? a.y : b.x, sz ? a.z : b.y, o, inv, okL, teL);
-            slab(sx ? c.y : b.z, sy ? c.z : b.w, sz ? c.w : c.x, sx ? b.z : c.y, sy ? b.w : c.z, sz ? c.x : c.w, o, inv, okR, teR);
+            if (fast) {
+                slab_fast(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, okL, teL);
+                slab_fast(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, okR, teR);
+            } else {
+                slab(sx ? a.w : a.x, sy ? b.x : a.y, sz ? b.y : a.z, sx ? a.x : a.w, sy ? a.y : b.x, sz ? a.z : b.y, o, inv, okL, teL);
+                slab(sx ? c.y : b.z, sy ? c.z : b.w, sz ? c.w : c.x, sx ? b.z : c.y, sy ? b.w : c.z, sz ? c.x : c.w, o, inv, okR, teR);
+            }
             int refL = __float_as_int(m.x), refR = __float_as_int(m.y);
             bool rightFirst = ((signbits >> __float_as_int(m.z)) & 1u) != 0u;
             int refN = rightFirst ? refR : refL, refF = rightFirst ? refL : refR;
@@ -297,6 +213,7 @@ struct Trav {
             } else {
                 pop_next();
             }
+            if (DEFER && st.full) alive = false;
         } else {
             if (COUNT) n_tris += 1;
             float ox = (a.x * o.x + a.y * o.y + a.z * o.z) + a.w;

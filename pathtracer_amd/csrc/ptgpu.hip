@@ -51,6 +51,8 @@ struct ptgpu_context {
     ptgpu_light* d_lights = nullptr;
     std::vector<ptgpu_light> h_lights;  // what d_lights holds
     float4* d_spill = nullptr;
+    int32_t* d_defer = nullptr;    // indices of the rays a one-ray-per-lane launch gave up for lack of LDS stack
+    size_t defer_capacity = 0;
     uint2* d_stack_ovf = nullptr;  // global-memory overflow of the per-lane traversal stacks (trees deeper than the LDS stack)
     size_t stack_ovf_bytes = 0;
 };
@@ -73,6 +75,11 @@ struct ptgpu_scene {
     int32_t num_materials = 0, num_textures = 0;
     uint64_t bytes[4] = {0, 0, 0, 0};
 };
+
+// zero a few counter words with plain stores (the form measured to be visible to a later kernel's atomics on this stream)
+__global__ void k_zero_words(unsigned long long* p, int count) {
+    if ((int)threadIdx.x < count) p[threadIdx.x] = 0ull;
+}
 
 extern "C" const char* ptgpu_last_error(void) { return g_err; }
 
@@ -106,6 +113,7 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     if (c->d_lights) hipFree(c->d_lights);
     if (c->d_spill) hipFree(c->d_spill);
     if (c->d_stack_ovf) hipFree(c->d_stack_ovf);
+    if (c->d_defer) hipFree(c->d_defer);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return PTGPU_OK;
@@ -191,7 +199,8 @@ extern "C" int ptgpu_debug_counters(ptgpu_context* c, unsigned long long* out32)
 extern "C" int ptgpu_reset_counters(ptgpu_context* c) {
     if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));  // spill words are cleared per pass
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters, 3);  // spill / defer words are cleared per use
+    HIP_TRY(hipGetLastError());
     return PTGPU_OK;
 }
 
@@ -254,6 +263,8 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
             seen[it.node] = 1;
             const ptgpu_flatnode& n = d->nodes[it.node];
             if (it.depth > depth) depth = it.depth;
+            for (int k = 0; k < 3; ++k)  // the NaN-free slab test of the kernels relies on this
+                if (n.bmin[k] != n.bmin[k] || n.bmax[k] != n.bmax[k]) return fail(PTGPU_E_INVALID, "node %d: NaN in its bounding box", it.node);
             if (n.leaf) {
                 if (n.startIdx != next_list || n.endIdx < n.startIdx || n.endIdx >= nl)
                     return fail(PTGPU_E_INVALID, "leaf %d: range [%d,%d] does not continue the list at %d", it.node, n.startIdx, n.endIdx, next_list);
@@ -375,29 +386,40 @@ extern "C" int ptgpu_scene_stats(const ptgpu_scene* s, uint64_t out_bytes[4], in
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-constexpr int RC_BLOCK = 256;  // 4 waves
+constexpr int RC_BLOCK = 256;      // persistent raycast kernel: 4 long-lived waves per workgroup
+// One-ray-per-lane kernel: ONE wave per workgroup.  A workgroup keeps its LDS and wave slots until its slowest wave ends, so
+// with 4 waves the three faster ones idle; measured on the configs[1] frame 64 vs 256 threads: closest 0.153 vs 0.160 ms,
+// any-hit 0.188 vs 0.236 ms, incoherent 0.296 vs 0.375 ms.
+constexpr int RC_STEP_BLOCK = 64;
 
 // One ray per lane for the lane's whole life (no refill), step-wise traverser.  Only built without stack overflow: a grid of
 // n/256 workgroups has no bounded set of waves to give overflow space to; deep trees use k_raycast_persist.
-template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS>
-__global__ __launch_bounds__(RC_BLOCK) void k_raycast_step(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
+// DEFER: the tree may need more than NLDS entries; a ray that does is given up here (nothing written out of bounds) and its index
+// appended to defer_list (count in counters[5]) for k_raycast_persist's overflow variant to trace.
+template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool DEFER>
+__global__ __launch_bounds__(RC_STEP_BLOCK) void k_raycast_step(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
                                                            long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
-                                                           float* __restrict__ out_u, float* __restrict__ out_v, unsigned long long* counters) {
-    __shared__ uint2 lds_stack[RC_BLOCK / 64][NLDS][64];
+                                                           float* __restrict__ out_u, float* __restrict__ out_v, unsigned long long* counters,
+                                                           int32_t* __restrict__ defer_list) {
+    __shared__ uint2 lds_stack[RC_STEP_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long i = (long long)blockIdx.x * RC_BLOCK + threadIdx.x;
-    ptd::Trav<ALPHA, COUNT, NLDS, false> tr;
+    long long i = (long long)blockIdx.x * RC_STEP_BLOCK + threadIdx.x;
+    ptd::Trav<ALPHA, COUNT, NLDS, false, DEFER> tr;
     tr.reset_counts();
     tr.attach(&lds_stack[wave][0][lane], nullptr);
     tr.alive = false;
     if (i < n) {
         tr.begin(S, ptd::ld3(orig + i * 3), ptd::ld3(dir + i * 3), ANYHIT);
         while (tr.alive) tr.step(S);
-        ptd::HitRec h = tr.result(S);
-        if (out_id) out_id[i] = h.id;
-        if (out_t) out_t[i] = h.t;
-        if (out_u) out_u[i] = h.u;
-        if (out_v) out_v[i] = h.v;
+        if (tr.deferred()) {
+            defer_list[atomicAdd(&counters[5], 1ull)] = (int32_t)i;  // at most n entries: the list holds n
+        } else {
+            ptd::HitRec h = tr.result(S);
+            if (out_id) out_id[i] = h.id;
+            if (out_t) out_t[i] = h.t;
+            if (out_u) out_u[i] = h.u;
+            if (out_v) out_v[i] = h.v;
+        }
     }
     if (COUNT) {
         atomicAdd(&counters[1], (unsigned long long)tr.n_nodes);
@@ -416,7 +438,13 @@ template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
 __global__ __launch_bounds__(RC_BLOCK) void k_raycast_persist(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
                                                               long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
                                                               float* __restrict__ out_u, float* __restrict__ out_v,
-                                                              unsigned long long* counters, int refill_threshold, uint2* stack_ovf) {
+                                                              unsigned long long* counters, int refill_threshold, uint2* stack_ovf,
+                                                              const int32_t* __restrict__ ray_index) {
+    // ray_index != NULL: trace rays ray_index[0 .. counters[5]) (the rays k_raycast_step deferred) instead of 0 .. n
+    if (ray_index) {
+        const unsigned long long m = counters[5];  // written by an earlier kernel on this stream
+        n = (long long)(m < (unsigned long long)n ? m : (unsigned long long)n);
+    }
     __shared__ uint2 lds_stack[RC_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long total_waves = (long long)gridDim.x * (RC_BLOCK / 64);
@@ -457,7 +485,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast_persist(ptd::TravScene S, 
                 int avail = (int)(end - next);
                 int rank = __popcll(need & ((1ull << lane) - 1ull));  // position of this lane among the lanes that need a ray
                 if ((ray < 0) && (rank < avail)) {
-                    ray = next + rank;
+                    ray = ray_index ? (long long)ray_index[next + rank] : next + rank;
                     tr.begin(S, ptd::ld3(orig + ray * 3), ptd::ld3(dir + ray * 3), ANYHIT);
                 }
                 int taken = __popcll(need) < avail ? __popcll(need) : avail;
@@ -497,9 +525,11 @@ static int ensure_stack_overflow(ptgpu_context* c, size_t bytes) {
 }
 
 template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
-static int launch_rc_persist(ptgpu_scene* s, const ptd::TravScene& trav, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
+static int launch_rc_persist(ptgpu_scene* s, const ptd::TravScene& trav, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v,
+                             const int32_t* ray_index = nullptr, long long expected = -1) {
     ptgpu_context* c = s->ctx;
-    long long want = (n + RC_CHUNK - 1) / RC_CHUNK;  // no more waves than chunks
+    long long want = ((expected >= 0 ? expected : n) + RC_CHUNK - 1) / RC_CHUNK;  // no more waves than chunks
+    if (want < 1) want = 1;
     long long blocks = (want + (RC_BLOCK / 64) - 1) / (RC_BLOCK / 64);
     // a small multiple of the blocks resident at once (LDS-limited): long-lived waves, dispatcher-level balancing
     static int per_cu = 0;
@@ -515,7 +545,7 @@ static int launch_rc_persist(ptgpu_scene* s, const ptd::TravScene& trav, const f
         if (rc != PTGPU_OK) return rc;
     }
     hipLaunchKernelGGL((k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(RC_BLOCK), 0, c->stream, trav, o, d, n, id, t,
-                       u, v, c->d_counters, env_int("PTGPU_RAYCAST_REFILL", 32), c->d_stack_ovf);
+                       u, v, c->d_counters, env_int("PTGPU_RAYCAST_REFILL", 32), c->d_stack_ovf, ray_index);
     return PTGPU_OK;
 }
 
@@ -527,15 +557,40 @@ static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long l
     // stack occupancy <= depth - 1 (one far sibling per ancestor level); the counting variant pushes every far child as well
     const int need = s->depth - 1;
     const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", 24);
-    dim3 grid((unsigned)((n + RC_BLOCK - 1) / RC_BLOCK)), block(RC_BLOCK);
+    dim3 grid((unsigned)((n + RC_STEP_BLOCK - 1) / RC_STEP_BLOCK)), block(RC_STEP_BLOCK);
     if constexpr (COUNT || ALPHA) {  // rare variants: one configuration that is valid for every depth
         return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
     } else {
-        if (need > 24 || (need > 16 && nlds == 16)) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
-        if (impl == 2) return nlds == 16 ? launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, false>(s, trav, o, d, n, id, t, u, v)
-                                         : launch_rc_persist<ANYHIT, ALPHA, COUNT, 24, false>(s, trav, o, d, n, id, t, u, v);
-        if (nlds == 16) hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 16>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters);
-        else hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 24>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters);
+        if (impl == 2) {
+            if (need > 24 || (need > 16 && nlds == 16)) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
+            return nlds == 16 ? launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, false>(s, trav, o, d, n, id, t, u, v)
+                              : launch_rc_persist<ANYHIT, ALPHA, COUNT, 24, false>(s, trav, o, d, n, id, t, u, v);
+        }
+        // one ray per lane.  If the tree could need more stack than the LDS holds, rays that actually do are deferred to a
+        // second, persistent launch with global-memory overflow (they are rare: occupancy stays < 16 for almost every ray).
+        const bool defer = need > nlds;
+        if (defer) {
+            if (n > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large for the deferred-ray list");
+            if ((size_t)n > c->defer_capacity) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (c->d_defer) { HIP_TRY(hipFree(c->d_defer)); c->d_defer = nullptr; c->defer_capacity = 0; }
+                HIP_TRY(hipMalloc(&c->d_defer, (size_t)n * sizeof(int32_t)));
+                c->defer_capacity = (size_t)n;
+            }
+            hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + 5, 1);
+        }
+        if (nlds == 16) {
+            if (defer) hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 16, true>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
+            else hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 16, false>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
+        } else {
+            if (defer) hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 24, true>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
+            else hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 24, false>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
+        }
+        if (defer) {
+            // the number of deferred rays is only known on the device: a small fixed grid, the kernel reads the count itself
+            const long long expected = n / 64 < 65536 ? 65536 : n / 64;
+            return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v, c->d_defer, expected < n ? expected : n);
+        }
         return PTGPU_OK;
     }
 }
@@ -546,7 +601,7 @@ extern "C" int ptgpu_raycast_batch_dev(ptgpu_scene* s, int use_alpha, const floa
     if (n < 0) return fail(PTGPU_E_INVALID, "n < 0");
     if (n == 0) return PTGPU_OK;
     if (!d_orig || !d_dir) return fail(PTGPU_E_INVALID, "ray arrays are NULL");
-    if ((n + RC_BLOCK - 1) / RC_BLOCK > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large for one launch");
+    if ((n + RC_STEP_BLOCK - 1) / RC_STEP_BLOCK > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large for one launch");
     HIP_TRY(hipSetDevice(s->ctx->device));
     const bool alpha = use_alpha && s->has_alpha, count = s->ctx->count;
     int rc;
@@ -902,7 +957,7 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
         else rc = launch_integrate<false, 24, false>(s, trav, ss, prm, cam, pd);
         if (rc != PTGPU_OK) return rc;
         if (prm->sobol_block) {
-            HIP_TRY(hipMemsetAsync(c->d_counters + 3, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + 3, 1);
             hipLaunchKernelGGL(k_accum_sobol, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum, c->d_spill, c->d_counters);
             hipLaunchKernelGGL(k_apply_spill, dim3(1), dim3(64), 0, c->stream, *prm, c->d_spill, d_accum, c->d_counters);
         } else {
