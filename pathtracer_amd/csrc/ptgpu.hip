@@ -737,7 +737,10 @@ extern "C" int ptgpu_gen_shadow_dev(ptgpu_scene* s, const ptgpu_light* light, in
 //   k_apply_spill      Sobol-block samples whose pixel lies outside their own block (sobol() rounds to 1.0f)
 //   k_resolve          updatePicture (:855-871)
 // ------------------------------------------------------------------------------------------------
-constexpr int PT_BLOCK = 256;
+#ifndef PT_BLOCK_THREADS
+#define PT_BLOCK_THREADS 64  // one wave per workgroup (measured 64 / 128 / 256: 30.3 / 30.7 / 31.0 ms per 16 spp pass)
+#endif
+constexpr int PT_BLOCK = PT_BLOCK_THREADS;
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (launch_bounds 2nd argument): <= 128 VGPRs.
                         // Measured on the configs[2] frame: 4 waves + 16 LDS stack entries 32.0 ms vs 3 waves + 24 entries 34.6 ms per 16 spp
@@ -894,14 +897,14 @@ static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const pt
     }
     const long long total = (long long)pd.num_blocks * pd.samples_per_block;
     long long blocks = (total + PT_BLOCK - 1) / PT_BLOCK;
-    const long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_PT_OVERSUB", 1);
+    const long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_PT_OVERSUB", 4);
     if (blocks > resident) blocks = resident;
     if (OVF) {
         int rc = ensure_stack_overflow(c, (size_t)blocks * (PT_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
         if (rc != PTGPU_OK) return rc;
     }
     hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
-                       c->d_counters, env_int("PTGPU_PT_SERVICE", 40), c->d_stack_ovf);
+                       c->d_counters, env_int("PTGPU_PT_SERVICE", 32), c->d_stack_ovf);
     return PTGPU_OK;
 }
 
