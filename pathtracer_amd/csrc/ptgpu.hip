@@ -556,7 +556,11 @@ static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long l
     trav.alpha_on = ALPHA ? 1 : 0;
     // stack occupancy <= depth - 1 (one far sibling per ancestor level); the counting variant pushes every far child as well
     const int need = s->depth - 1;
-    const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", 24);
+    // LDS stack entries per lane: 24 (13 waves/CU, never overflows up to depth 25) wins while the tree sits in one XCD's L2;
+    // 16 (20 waves/CU, deeper rays deferred) wins once fetches leave L2 -- measured: head 0.153 vs 0.165 ms, 262k-triangle
+    // atrium 1.55 vs 1.33 ms, 10M-triangle cloud 2.96 vs 2.32 ms (closest-hit frames).
+    const bool small_scene = s->bytes[0] + s->bytes[1] <= (4u << 20) && need <= 24;
+    const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : 16);
     dim3 grid((unsigned)((n + RC_STEP_BLOCK - 1) / RC_STEP_BLOCK)), block(RC_STEP_BLOCK);
     if constexpr (COUNT || ALPHA) {  // rare variants: one configuration that is valid for every depth
         return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
