@@ -392,8 +392,8 @@ constexpr int RC_BLOCK = 256;      // persistent raycast kernel: 4 long-lived wa
 // any-hit 0.188 vs 0.236 ms, incoherent 0.296 vs 0.375 ms.
 constexpr int RC_STEP_BLOCK = 64;
 
-// One ray per lane for the lane's whole life (no refill), step-wise traverser.  Only built without stack overflow: a grid of
-// n/256 workgroups has no bounded set of waves to give overflow space to; deep trees use k_raycast_persist.
+// One ray per lane for the lane's whole life (no refill), step-wise traverser.  Never built with global-memory stack overflow:
+// a grid of n/64 workgroups has no bounded set of waves to give overflow regions to.
 // DEFER: the tree may need more than NLDS entries; a ray that does is given up here (nothing written out of bounds) and its index
 // appended to defer_list (count in counters[5]) for k_raycast_persist's overflow variant to trace.
 template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool DEFER>
@@ -508,8 +508,8 @@ __global__ void k_add_rays(unsigned long long* counters, unsigned long long n) {
 
 // Kernel selection.  PTGPU_RAYCAST_IMPL (1 = step-wise, one ray per lane; 2 = persistent step-wise with refill) and
 // PTGPU_RAYCAST_NLDS (16 / 24 LDS stack entries per lane) exist for A/B timing in one process (read at every launch).  Every
-// variant produces identical hit records.  Trees deeper than the LDS stack always take the persistent kernel, whose bounded
-// set of waves owns a global-memory overflow region each.
+// variant produces identical hit records.  For trees deeper than the LDS stack the one-ray-per-lane kernel defers the (rare) rays that
+// actually overflow to a persistent launch, whose bounded set of waves owns a global-memory overflow region each.
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
