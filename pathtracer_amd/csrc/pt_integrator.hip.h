@@ -216,11 +216,20 @@ __device__ __forceinline__ int block_sobol_base(int idx, uint32_t pass_seed) {
 #endif
 
 // per-lane path state between two service rounds
-enum : int { ST_IDLE = 0, ST_EXT = 1, ST_SH = 2, ST_BOUNCE = 3, ST_WSHADOW = 4 };
+//   ST_EXT      closest-hit ray in flight, or finished and waiting for the hit block
+//   ST_SH       shadow ray in flight; for path tracing everything that follows it is already decided (see "pending bounce")
+//   ST_BOUNCE   waits for a bounce ray from the hit point it already has (miss inside the fixed-bounce loop, then roulette)
+//   ST_REBOUNCE the same, but throughput is already updated (pending bounce discarded because the normal was flipped)
+//   ST_WSHADOW  Whitted: waits for its next light ray;  ST_FIN: transient result of advance()
+enum : int { ST_IDLE = 0, ST_EXT = 1, ST_SH = 2, ST_BOUNCE = 3, ST_WSHADOW = 4, ST_REBOUNCE = 5, ST_FIN = 6 };
+enum : uint32_t { PB_PENDING = 64u, PB_BACKFACING = 128u };  // above Trav::Prepared's bits
 
 struct PathState {
-    F3 O, N, V, diffuse, specular, throughput, Ei, emission, L;
-    float gloss, normalization, pdf, terminate, aux;  // aux: 4th output word (local pixel bits or Gaussian weight)
+    F3 O, N, V, diffuse, throughput, Ei, emission;
+    F3 c;      // path tracing: radiance this hit adds if its shadow ray is unoccluded; Whitted: the specular colour
+    F3 inv_n;  // pending bounce ray: reciprocal direction
+    uint32_t bits;  // pending bounce ray: Trav::Prepared::bits | PB_*
+    float gloss, normalization, terminate, aux;  // aux: 4th output word (local pixel bits or Gaussian weight)
     int li, bounce, base, mode, stage;
     long long sid;
     Rng R;
@@ -260,7 +269,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
         ps.sid = -1;
     };
     // loop control of tracePath between two rays: 1 = fixed-bounce loop test (:389), 2 = roulette entry (:466-468),
-    // 3 = roulette loop test (:471).  Leaves the lane waiting for a bounce ray (ST_BOUNCE) or finishes the sample.
+    // 3 = roulette loop test (:471).  Leaves the lane asking for a bounce ray (ST_BOUNCE) or at the end of its path (ST_FIN).
     auto advance = [&](int next_ctl) {
         if (next_ctl == 1) {
             if (ps.bounce < bounces) { ps.mode = 1; ps.stage = ST_BOUNCE; return; }
@@ -268,10 +277,10 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
         }
         if (next_ctl == 2) {
             if (prm.bounces < 0) { ps.terminate = ps.R.getF32(0.0f, 1.0f); next_ctl = 3; }
-            else { finish(); return; }
+            else { ps.stage = ST_FIN; return; }
         }
         if (ps.terminate > prm.termination_prob) { ps.mode = 2; ps.stage = ST_BOUNCE; }
-        else finish();
+        else ps.stage = ST_FIN;
     };
 
 #ifdef PT_STAMPS
@@ -289,35 +298,63 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
         float x, y;
         map_to_disk(a, b, x, y);
         F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * x + light_col(Lt, 1) * y;
-        ps.L = Pl - ps.O;
-        F3 D = normalize(ps.L);
-        tr.begin(TS, ps.O + 0.0001f * D, ps.L, true);  // origin offset along D here, not N (:634)
+        F3 L = Pl - ps.O;
+        F3 D = normalize(L);
+        tr.begin(TS, ps.O + 0.0001f * D, L, true);  // origin offset along D here, not N (:634)
         n_rays += 1;
         ps.stage = ST_SH;
     };
 
     // Wave-uniform scheduling.  A lane is traversing (alive) or waits for ONE of three service blocks:
-    //   H  hit set-up after a closest-hit ray that hit  (texture parameters, light choice, light sample, shadow ray)
-    //   S  shade after a shadow ray + loop control + bounce set-up (also lanes whose bounce ray missed and go on to roulette)
+    //   H  after a closest-hit ray that hit: texture parameters, light choice, light sample, shadow ray, AND everything the reference
+    //      does after the shadow ray except adding the light's contribution: the contribution itself (kept in ps.c), the loop control
+    //      with its random draws, and the bounce ray (kept pending: direction in ps.V, reciprocal in ps.inv_n).  None of that depends
+    //      on the shadow ray's outcome, with one exception (below), and the sample's random stream is consumed in the same order.
+    //      Lanes that only need a bounce ray from the hit point they already have (ST_BOUNCE / ST_REBOUNCE) are served here too.
+    //   S  Whitted only: count the light ray, next light ray or final colour
     //   N  retire / new sample
-    // The wave runs the block most lanes wait for once that count reaches service_threshold (or exceeds the traversing lanes),
-    // so each block runs with many of its lanes; otherwise all traversing lanes take one step.  Classification is redone only
-    // when a ray has finished or a block has run.
+    // When a path-tracing shadow ray ends, the cheap control section adds ps.c if it was unoccluded and either finishes the sample or
+    // launches the pending bounce ray -- no second wait for a service block.  The exception: the reference flips the shading normal of a
+    // back-facing hit only inside its "unoccluded" branch (:346-353), and the bounce leaves along the normal; for a back-facing,
+    // unoccluded hit the pending bounce (built from the unflipped normal) is discarded and the lane asks for a new one (ST_REBOUNCE).
+    // The wave runs the block most lanes wait for once that count reaches service_threshold (or exceeds the traversing lanes), so each
+    // block runs with many of its lanes; otherwise all traversing lanes take one step.  Classification is redone only when a ray has
+    // finished or a block has run.
     bool dirty = true;
     unsigned long long prev_alive = 0ull;
     for (;;) {
-        const unsigned long long alive_mask = __ballot(tr.alive);
+        unsigned long long alive_mask = __ballot(tr.alive);
         if (dirty || alive_mask != prev_alive) {
             PT_STAMP_BEGIN();
             dirty = false;
-            // cheap control: closest-hit rays that missed
-            if (!tr.alive && ps.stage == ST_EXT && tr.pmin < 0) {
-                if (ps.mode == 1) advance(2);  // miss inside the fixed-bounce loop: `break`, then the roulette section
-                else finish();                 // primary miss (Ei = 0), or miss inside the roulette loop
+            if (!tr.alive && ps.stage == ST_SH && ps.mode != 3) {
+                // shadow ray of a path-tracing hit: reference :346-376 / :416-450 / :500-534 reduced to their outcome
+                const bool unoccluded = tr.pmin < 0;
+                if (unoccluded) ps.Ei = ps.Ei + ps.c;
+                if (!(ps.bits & PB_PENDING)) finish();
+                else if (unoccluded && (ps.bits & PB_BACKFACING)) {
+                    ps.N = ps.N * -1.0f;
+                    ps.stage = ST_REBOUNCE;
+                } else {
+                    typename Trav<true, COUNT, NLDS, OVF>::Prepared pr;
+                    pr.inv = ps.inv_n;
+                    pr.bits = ps.bits;
+                    tr.launch(TS, ps.O + 0.0001f * ps.N, cam.far_ * ps.V, pr, false);
+                    n_rays += 1;
+                    ps.stage = ST_EXT;
+                }
             }
+            // closest-hit ray that missed (after the section above: a bounce ray launched there may miss the scene's box at once)
+            if (!tr.alive && ps.stage == ST_EXT && tr.pmin < 0) {
+                if (ps.mode == 1) {  // inside the fixed-bounce loop: `break`, then the roulette section
+                    advance(2);
+                    if (ps.stage == ST_FIN) finish();
+                } else finish();     // primary miss (Ei = 0), or miss inside the roulette loop
+            }
+            alive_mask = __ballot(tr.alive);
             const int nA = __popcll(alive_mask);
-            const int nH = __popcll(__ballot(!tr.alive && ps.stage == ST_EXT));
-            const int nS = __popcll(__ballot((!tr.alive && ps.stage == ST_SH) || ps.stage == ST_BOUNCE));
+            const int nH = __popcll(__ballot((!tr.alive && ps.stage == ST_EXT) || ps.stage == ST_BOUNCE || ps.stage == ST_REBOUNCE));
+            const int nS = __popcll(__ballot(!tr.alive && ps.stage == ST_SH));  // Whitted only: other shadow rays were settled above
             const int nN = exhausted ? 0 : __popcll(__ballot(ps.stage == ST_IDLE));
             if (nA == 0 && nH + nS + nN == 0) break;  // sample range exhausted and every lane idle
             int best = nH;
@@ -327,7 +364,9 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
             PT_STAMP_END(0, nH + nS + nN);
             if (run && nH == best) {
                 PT_STAMP_BEGIN();
-                if (!tr.alive && ps.stage == ST_EXT) {
+                const bool hit_lane = !tr.alive && ps.stage == ST_EXT;
+                bool want_bounce = ps.stage == ST_BOUNCE || ps.stage == ST_REBOUNCE;
+                if (hit_lane) {
                     // hit set-up: reference :300-344 (first hit), :403-414 / :486-498 (bounce hits), :608-613 (Whitted)
                     const float4 rec = TS.tris[(size_t)tr.pmin * 4 + 3];
                     const int hit_tri = __float_as_int(rec.x), hit_mat = __float_as_int(rec.w);
@@ -340,9 +379,11 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         ps.V = normalize(tr.d);
                     }
                     ps.O = tr.o + tr.tmin * tr.d;
-                    get_texture_parameters(SS, prm, hit_tri, hit_mat, tr.umin, tr.vmin, ps.diffuse, ps.N, ps.specular);
+                    F3 specular;
+                    get_texture_parameters(SS, prm, hit_tri, hit_mat, tr.umin, tr.vmin, ps.diffuse, ps.N, specular);
                     ps.li = get_light_to_sample(ps.O, lights, pd.num_lights, ps.R);
                     if (prm.whitted) {
+                        ps.c = specular;
                         ps.terminate = 0.0f;  // "shadow": number of unoccluded light rays; ps.bounce = light-ray index
                         ps.mode = 3;
                         ps.stage = ST_WSHADOW;
@@ -356,68 +397,39 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         float lx = (2.0f * sa - 1.0f) * Lt.size[0];
                         float ly = (2.0f * sb - 1.0f) * Lt.size[1];
                         F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * lx + light_col(Lt, 1) * ly;
-                        ps.pdf = 1.0f / (4.0f * Lt.size[0] * Lt.size[1]);
-                        ps.L = Pl - ps.O;
+                        const float pdf = 1.0f / (4.0f * Lt.size[0] * Lt.size[1]);
+                        const F3 L = Pl - ps.O;
                         if (first) ps.emission = f3(Lt.E[0], Lt.E[1], Lt.E[2]) * prm.intensity;  // once per path (:341)
-                        tr.begin(TS, ps.O + 0.0001f * ps.N, ps.L, true);
+                        tr.begin(TS, ps.O + 0.0001f * ps.N, L, true);
                         n_rays += 1;
-                        ps.stage = ST_SH;
-                    }
-                    if (ps.stage == ST_WSHADOW) whitted_shadow();
-                }
-                PT_STAMP_END(2, nH);
-                dirty = true;
-            } else if (run && nS == best) {
-                PT_STAMP_BEGIN();
-                if (!tr.alive && ps.stage == ST_SH) {
-                    if (ps.mode == 3) {
-                        // traceWhitted's light-ray loop (reference :614-637): count unoccluded disk samples
-                        if (tr.pmin < 0) ps.terminate += 1.0f;
-                        ps.bounce += 1;
-                        if (ps.bounce < prm.num_light_rays) ps.stage = ST_WSHADOW;
-                        else {
-                            // reference :639-656
-                            const ptgpu_light& Lt = lights[ps.li];
-                            F3 L = light_col(Lt, 3) - ps.O;
+                        // what the light adds if the shadow ray finds nothing: reference :346-376 / :416-450 / :500-534
+                        {
                             F3 D = normalize(L);
-                            float d = length(L);
-                            float attenuation = prm.intensity / (prm.attenuation * ptm_pow(d, 2.0f) + prm.attenuation * d + 0.5f);
-                            F3 H = normalize(D - ps.V);
-                            F3 color = ps.diffuse * sel_max(0.0f, dot(ps.N, D));
-                            color = color + ps.specular * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
-                            color = color * attenuation;
-                            color = color * (ps.terminate / (float)prm.num_light_rays);
-                            ps.Ei = color;
-                            finish();
-                        }
-                    } else {
-                        if (tr.pmin < 0) {
-                            // unoccluded: reference :346-376 / :416-450 / :500-534
-                            const ptgpu_light& Lt = lights[ps.li];
-                            F3 D = normalize(ps.L);
                             F3 Nl = -light_col(Lt, 2);
-                            if (dot(ps.N, ps.V) > 0.0f) ps.N = ps.N * -1.0f;
-                            float cos_theta = sel_max(0.0f, dot(ps.N, D));
+                            const bool back = dot(ps.N, ps.V) > 0.0f;
+                            const F3 Nf = back ? ps.N * -1.0f : ps.N;
+                            float cos_theta = sel_max(0.0f, dot(Nf, D));
                             float cos_theta_l = sel_max(0.0f, dot(Nl, -D));
-                            float d = length(ps.L);
+                            float d = length(L);
                             float inv_d = sel_min(1.0f / (d * d), 100000.0f);
-                            float inv_pdf = sel_min(1.0f / ps.pdf, 100000.0f);
+                            float inv_pdf = sel_min(1.0f / pdf, 100000.0f);
                             F3 H = normalize(D - ps.V);
                             F3 color = ps.diffuse;
-                            color = color + ps.specular * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
+                            color = color + specular * ptm_pow(sel_max(0.0f, dot(Nf, H)), ps.gloss) * ps.normalization;
                             const float invPi = 0.31830988618379f;
-                            F3 c;
-                            if (ps.mode == 0) c = color * invPi * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
-                            else if (ps.mode == 1) c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
-                            else c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf * pd.inv_prob;
-                            ps.Ei = ps.Ei + c;
+                            if (ps.mode == 0) ps.c = color * invPi * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
+                            else if (ps.mode == 1) ps.c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
+                            else ps.c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf * pd.inv_prob;
+                            ps.bits = back ? PB_BACKFACING : 0u;
                         }
+                        // loop control after the shade (random draws in the reference's order)
                         if (ps.mode == 2) { ps.terminate = ps.R.getF32(0.0f, 1.0f); ps.bounce += 1; advance(3); }
                         else { if (ps.mode == 1) ps.bounce += 1; advance(1); }
+                        want_bounce = ps.stage == ST_BOUNCE;
                     }
                 }
                 if (ps.stage == ST_WSHADOW) whitted_shadow();
-                if (ps.stage == ST_BOUNCE) {
+                if (want_bounce) {
                     // reference :391-401 / :473-484; drawCosineWeightedDirection :57-73 (RNG peeked, not advanced)
                     int dim = 2 + 4 * sobol_bounce_dim(ps.bounce);
                     int rnd = ps.R.peekS32(1, 1234);
@@ -428,11 +440,45 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                     map_to_disk(a, b, x, y);
                     float z = sqrtf(1 - x * x - y * y);
                     ps.V = normalize(basis_times(ps.N, f3(x, y, z)));
-                    ps.throughput = ps.throughput * ps.diffuse;
-                    tr.begin(TS, ps.O + 0.0001f * ps.N, cam.far_ * ps.V, false);
-                    n_rays += 1;
-                    ps.stage = ST_EXT;
+                    if (ps.stage != ST_REBOUNCE) ps.throughput = ps.throughput * ps.diffuse;
+                    const F3 bo = ps.O + 0.0001f * ps.N, bd = cam.far_ * ps.V;
+                    const auto pr = Trav<true, COUNT, NLDS, OVF>::prepare(TS, bo, bd);
+                    if (hit_lane) {  // the shadow ray goes first
+                        ps.inv_n = pr.inv;
+                        ps.bits |= pr.bits | PB_PENDING;
+                    } else {
+                        tr.launch(TS, bo, bd, pr, false);
+                        n_rays += 1;
+                        ps.stage = ST_EXT;
+                    }
                 }
+                if (hit_lane && !prm.whitted) ps.stage = ST_SH;
+                PT_STAMP_END(2, nH);
+                dirty = true;
+            } else if (run && nS == best) {
+                PT_STAMP_BEGIN();
+                if (!tr.alive && ps.stage == ST_SH) {
+                    // traceWhitted's light-ray loop (reference :614-637): count unoccluded disk samples
+                    if (tr.pmin < 0) ps.terminate += 1.0f;
+                    ps.bounce += 1;
+                    if (ps.bounce < prm.num_light_rays) ps.stage = ST_WSHADOW;
+                    else {
+                        // reference :639-656
+                        const ptgpu_light& Lt = lights[ps.li];
+                        F3 L = light_col(Lt, 3) - ps.O;
+                        F3 D = normalize(L);
+                        float d = length(L);
+                        float attenuation = prm.intensity / (prm.attenuation * ptm_pow(d, 2.0f) + prm.attenuation * d + 0.5f);
+                        F3 H = normalize(D - ps.V);
+                        F3 color = ps.diffuse * sel_max(0.0f, dot(ps.N, D));
+                        color = color + ps.c * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
+                        color = color * attenuation;
+                        color = color * (ps.terminate / (float)prm.num_light_rays);
+                        ps.Ei = color;
+                        finish();
+                    }
+                }
+                if (ps.stage == ST_WSHADOW) whitted_shadow();
                 PT_STAMP_END(1, nS);
                 dirty = true;
             } else if (run) {

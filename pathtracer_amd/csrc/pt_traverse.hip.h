@@ -146,29 +146,44 @@ struct Trav {
     // DEFER: the ray ran out of LDS stack and was given up (alive is false, no result): re-trace it with an OVF kernel
     __device__ __forceinline__ bool deferred() const { return DEFER && st.full; }
 
-    __device__ __forceinline__ void begin(const TravScene& S, F3 o_, F3 d_, bool anyhit_) {
-        o = o_; d = d_; anyhit = anyhit_;
-        tmin = 1.0f; umin = 0.0f; vmin = 0.0f; pmin = -1;
-        inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-        signbits = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
+    // begin() in two halves, for a caller that prepares a ray while another one is still in flight: prepare() does everything that
+    // costs arithmetic (reciprocal direction, sign bits, the NaN-freedom flag, the root-box test), launch() installs the result.
+    struct Prepared {
+        F3 inv;
+        uint32_t bits;  // 0-2 sign of 1/dir, 3 fast, 4 root box entered, 5 scene not empty
+    };
+    __device__ __forceinline__ static Prepared prepare(const TravScene& S, F3 o_, F3 d_) {
+        Prepared p;
+        p.inv = f3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z);
+        const bool sx = p.inv.x < 0.0f, sy = p.inv.y < 0.0f, sz = p.inv.z < 0.0f;
+        p.bits = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
         {   // x * 0 == 0 exactly for finite x only; != 0 excludes 1/inf
-            const float z = inv.x * 0.0f + inv.y * 0.0f + inv.z * 0.0f + o.x * 0.0f + o.y * 0.0f + o.z * 0.0f;
-            fast = (z == 0.0f) && inv.x != 0.0f && inv.y != 0.0f && inv.z != 0.0f;
+            const float z = p.inv.x * 0.0f + p.inv.y * 0.0f + p.inv.z * 0.0f + o_.x * 0.0f + o_.y * 0.0f + o_.z * 0.0f;
+            if ((z == 0.0f) && p.inv.x != 0.0f && p.inv.y != 0.0f && p.inv.z != 0.0f) p.bits |= 8u;
         }
-        st.sp = 0;
-        st.full = false;
-        cur = S.root_ref;
-        alive = false;
         if (S.list_size > 0) {
             bool ok; float te;
             slab(sx ? S.root_bmax[0] : S.root_bmin[0], sy ? S.root_bmax[1] : S.root_bmin[1], sz ? S.root_bmax[2] : S.root_bmin[2],
                  sx ? S.root_bmin[0] : S.root_bmax[0], sy ? S.root_bmin[1] : S.root_bmax[1], sz ? S.root_bmin[2] : S.root_bmax[2],
-                 o, inv, ok, te);
-            alive = ok && (te < tmin);
-            if (COUNT) n_nodes += 1;
+                 o_, p.inv, ok, te);
+            if (ok && (te < 1.0f)) p.bits |= 16u;  // 1.0f: the ray's initial tmin
+            p.bits |= 32u;
         }
+        return p;
     }
+    __device__ __forceinline__ void launch(const TravScene& S, F3 o_, F3 d_, const Prepared& p, bool anyhit_) {
+        o = o_; d = d_; anyhit = anyhit_;
+        tmin = 1.0f; umin = 0.0f; vmin = 0.0f; pmin = -1;
+        inv = p.inv;
+        signbits = p.bits & 7u;
+        fast = (p.bits & 8u) != 0u;
+        st.sp = 0;
+        st.full = false;
+        cur = S.root_ref;
+        alive = (p.bits & 16u) != 0u;
+        if (COUNT && (p.bits & 32u)) n_nodes += 1;
+    }
+    __device__ __forceinline__ void begin(const TravScene& S, F3 o_, F3 d_, bool anyhit_) { launch(S, o_, d_, prepare(S, o_, d_), anyhit_); }
 
     __device__ __forceinline__ void pop_next() {
         alive = false;
