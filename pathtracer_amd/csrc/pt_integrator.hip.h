@@ -29,6 +29,7 @@ struct ShadeScene {
     const float* uv;   // [num_tris][3][2]
     const ptgpu_material* materials;
     const DevTexture* textures;
+    const uint2* sobol_pairs;  // [SOBOL_PAIRS][3][256], see sobol32x2
 };
 
 // work description of one integrator launch: blocks b = block_begin + (j0 + jj) * block_stride, jj in [0, num_blocks)
@@ -40,13 +41,23 @@ struct PassDesc {
     float inv_prob;            // 1 / m_terminationProbability (:468)
 };
 
+// x / 255.0f for x = 0, 1, ..., 255: one multiply and two fused steps give the correctly rounded quotient for every one of the 256
+// inputs (checked exhaustively in tests/test_oracle_cpu.py), i.e. the same float as the reference's IEEE division, in 3 instructions
+// instead of the ~10 of the general division sequence (18 of them per textured hit).
+__device__ __forceinline__ float div255(float x) {
+    const float y = 1.0f / 255.0f;
+    const float q = x * y;
+    const float r = __builtin_fmaf(-255.0f, q, x);
+    return __builtin_fmaf(r, y, q);
+}
+
 __device__ __forceinline__ F4 texel(const DevTexture& t, int x, int y) {
     x = x < 0 ? 0 : (x > t.width - 1 ? t.width - 1 : x);
     y = y < 0 ? 0 : (y > t.height - 1 ? t.height - 1 : y);
     const uint32_t p = *reinterpret_cast<const uint32_t*>(t.rgba + ((size_t)y * t.width + x) * 4);
     F4 r;
-    r.x = (float)(p & 0xffu) / 255.0f; r.y = (float)((p >> 8) & 0xffu) / 255.0f;
-    r.z = (float)((p >> 16) & 0xffu) / 255.0f; r.w = (float)(p >> 24) / 255.0f;
+    r.x = div255((float)(p & 0xffu)); r.y = div255((float)((p >> 8) & 0xffu));
+    r.z = div255((float)((p >> 16) & 0xffu)); r.w = div255((float)(p >> 24));
     return r;
 }
 __device__ __forceinline__ void texel_coords(F2 uv, const DevTexture& t, int& x, int& y) {
@@ -98,14 +109,21 @@ __device__ __forceinline__ float sobol32(uint32_t index, unsigned dimension) {
     for (unsigned i = 0; index; index >>= 1, ++i) result ^= row[i] & (0u - (index & 1u));
     return (float)result * (1.f / 4294967296.f);
 }
-// two consecutive dimensions of one index (the reference always draws them in pairs)
-__device__ __forceinline__ void sobol32x2(uint32_t index, unsigned dimension, float& a, float& b) {
-    unsigned ra = 0u, rb = 0u;
-    const uint32_t* row = g_sobol_matrices + dimension * 52u;
-    for (unsigned i = 0; index; index >>= 1, ++i) {
-        uint32_t m = 0u - (index & 1u);
-        ra ^= row[i] & m;
-        rb ^= row[i + 52] & m;
+// two consecutive dimensions (dimension even) of one index -- the reference always draws them in pairs.  The low 24 index bits go
+// through the byte table (ptgpu.hip k_build_sobol_pairs), any higher bits through sobol::sample's bit loop.
+constexpr int SOBOL_PAIRS = 512;
+__device__ __forceinline__ void sobol32x2(const uint2* __restrict__ tab, uint32_t index, unsigned dimension, float& a, float& b) {
+    const uint2* t = tab + (size_t)(dimension >> 1) * 768;
+    const uint2 e0 = t[index & 255u], e1 = t[256u + ((index >> 8) & 255u)], e2 = t[512u + ((index >> 16) & 255u)];
+    unsigned ra = e0.x ^ e1.x ^ e2.x, rb = e0.y ^ e1.y ^ e2.y;
+    index >>= 24;
+    if (index) {
+        const uint32_t* row = g_sobol_matrices + dimension * 52u + 24u;
+        for (unsigned i = 0; index; index >>= 1, ++i) {
+            uint32_t m = 0u - (index & 1u);
+            ra ^= row[i] & m;
+            rb ^= row[i + 52] & m;
+        }
     }
     a = (float)ra * (1.f / 4294967296.f);
     b = (float)rb * (1.f / 4294967296.f);
@@ -292,7 +310,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
         const ptgpu_light& Lt = lights[ps.li];
         int r = ps.R.getS32(1, 1000);
         float sa, sb;
-        sobol32x2((uint32_t)(ps.base + r), 4u, sa, sb);
+        sobol32x2(SS.sobol_pairs, (uint32_t)(ps.base + r), 4u, sa, sb);
         float a = (2.0f * sa - 1.0f) * Lt.size[0];
         float b = (2.0f * sb - 1.0f) * Lt.size[1];
         float x, y;
@@ -393,7 +411,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         int dim = 4 + 4 * sobol_bounce_dim(ps.bounce);
                         int r = ps.R.getS32(1, 10000);
                         float sa, sb;
-                        sobol32x2((uint32_t)(ps.base + r), (unsigned)dim, sa, sb);
+                        sobol32x2(SS.sobol_pairs, (uint32_t)(ps.base + r), (unsigned)dim, sa, sb);
                         float lx = (2.0f * sa - 1.0f) * Lt.size[0];
                         float ly = (2.0f * sb - 1.0f) * Lt.size[1];
                         F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * lx + light_col(Lt, 1) * ly;
@@ -434,7 +452,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                     int dim = 2 + 4 * sobol_bounce_dim(ps.bounce);
                     int rnd = ps.R.peekS32(1, 1234);
                     float sa, sb;
-                    sobol32x2((uint32_t)(ps.base + rnd), (unsigned)dim, sa, sb);
+                    sobol32x2(SS.sobol_pairs, (uint32_t)(ps.base + rnd), (unsigned)dim, sa, sb);
                     float a = 2.0f * sa - 1.0f, b = 2.0f * sb - 1.0f;
                     float x, y;
                     map_to_disk(a, b, x, y);
@@ -511,7 +529,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                             const int i = s;
                             valid = i < bw * bh * prm.num_aa_rays;
                             float sa, sb;
-                            sobol32x2((uint32_t)(base + i), 0u, sa, sb);
+                            sobol32x2(SS.sobol_pairs, (uint32_t)(base + i), 0u, sa, sb);
                             px = (float)bx + (float)bw * sa;
                             py = (float)by + (float)bh * sb;
                             sbase = base + i;
@@ -524,7 +542,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                             valid = i < bw * bh;
                             const int pixel_x = bx + (i % bw), pixel_y = by + (i / bw);
                             float sa, sb;
-                            sobol32x2((uint32_t)(base + i + k), 0u, sa, sb);
+                            sobol32x2(SS.sobol_pairs, (uint32_t)(base + i + k), 0u, sa, sb);
                             float a = prm.filter_width * (sa - 0.5f) + 0.5f;
                             float b = prm.filter_width * (sb - 0.5f) + 0.5f;
                             px = (float)pixel_x + a;

@@ -55,6 +55,7 @@ struct ptgpu_context {
     size_t defer_capacity = 0;
     uint2* d_stack_ovf = nullptr;  // global-memory overflow of the per-lane traversal stacks (trees deeper than the LDS stack)
     size_t stack_ovf_bytes = 0;
+    uint2* d_sobol_pairs = nullptr;  // byte-indexed Sobol table for the integrator (pt_integrator.hip.h sobol32x2), built at init
 };
 constexpr int CTR_WORDS = 32;  // [0..2] public counters, [3..4] spill list, [8..28] diagnostic stamps (PT_STAMPS builds)
 constexpr int SPILL_CAPACITY = 1 << 16;
@@ -81,6 +82,19 @@ __global__ void k_zero_words(unsigned long long* p, int count) {
     if ((int)threadIdx.x < count) p[threadIdx.x] = 0ull;
 }
 
+// tab[(pair * 3 + k) * 256 + b] = XOR of the direction numbers of dimensions (2*pair, 2*pair + 1) selected by the bits of byte b at
+// index bits 8k .. 8k+7: three gathers replace up to 24 iterations of sobol::sample's bit loop (XOR is associative: same word).
+__global__ void k_build_sobol_pairs(uint2* tab) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ptd::SOBOL_PAIRS * 3 * 256) return;
+    const int b = e & 255, k = (e >> 8) % 3, pair = (e >> 8) / 3;
+    const uint32_t* row = ptd::g_sobol_matrices + (size_t)pair * 2 * 52 + 8 * k;
+    uint32_t ra = 0u, rb = 0u;
+    for (int j = 0; j < 8; ++j)
+        if ((b >> j) & 1) { ra ^= row[j]; rb ^= row[j + 52]; }
+    tab[e] = make_uint2(ra, rb);
+}
+
 extern "C" const char* ptgpu_last_error(void) { return g_err; }
 
 extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
@@ -100,6 +114,13 @@ extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
     HIP_TRY(hipMalloc(&c->d_counters, CTR_WORDS * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_counters, 0, CTR_WORDS * sizeof(unsigned long long)));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        const int entries = ptd::SOBOL_PAIRS * 3 * 256;
+        HIP_TRY(hipMalloc(&c->d_sobol_pairs, (size_t)entries * sizeof(uint2)));
+        hipLaunchKernelGGL(k_build_sobol_pairs, dim3((entries + 255) / 256), dim3(256), 0, c->stream, c->d_sobol_pairs);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     *out_ctx = c;
     return PTGPU_OK;
 }
@@ -114,6 +135,7 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     if (c->d_spill) hipFree(c->d_spill);
     if (c->d_stack_ovf) hipFree(c->d_stack_ovf);
     if (c->d_defer) hipFree(c->d_defer);
+    if (c->d_sobol_pairs) hipFree(c->d_sobol_pairs);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return PTGPU_OK;
@@ -951,6 +973,7 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     trav.alpha_on = (prm->use_alpha && s->has_alpha) ? 1 : 0;
     ptd::ShadeScene ss;
     ss.pos = s->d_pos; ss.nrm = s->d_nrm; ss.uv = s->d_uv; ss.materials = s->d_materials; ss.textures = s->d_textures;
+    ss.sobol_pairs = c->d_sobol_pairs;
     const int stack_need = s->depth - 1, nlds = env_int("PTGPU_PT_NLDS", 16);
     for (int j0 = 0; j0 < count; j0 += (int)batch_blocks) {
         ptd::PassDesc pd;

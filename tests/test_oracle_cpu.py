@@ -194,3 +194,35 @@ def test_libm_vs_portable_render_rmse(soup, oracle):
     b, _ = oracle.render_pass(soup["sd"], p, cam, [light], libm=True)
     rmse = np.sqrt(((a[..., :3] - b[..., :3]) ** 2).mean())
     assert rmse <= 1e-3 * max(b[..., :3].mean(), 1e-6) + 1e-6
+
+
+def test_div255_three_step_form_is_the_ieee_quotient():
+    """pt_integrator.hip.h div255(): q = x*y; r = fma(-255, q, x); q' = fma(r, y, q) with y = RN(1/255) must equal RN(x/255) for
+    every texel byte value (exact rational arithmetic, one rounding per operation)."""
+    from fractions import Fraction as F
+    import math
+
+    def rn(fr):  # round to nearest float32, ties to even (normal range)
+        if fr == 0:
+            return F(0)
+        sgn, a = (1 if fr > 0 else -1), abs(fr)
+        e = math.floor(math.log2(float(a)))
+        while F(2) ** e > a:
+            e -= 1
+        while F(2) ** (e + 1) <= a:
+            e += 1
+        ulp = F(2) ** (e - 23)
+        q = a / ulp
+        n = q.numerator // q.denominator
+        rem = q - n
+        if rem > F(1, 2) or (rem == F(1, 2) and n % 2 == 1):
+            n += 1
+        return sgn * n * ulp
+
+    y = rn(F(1, 255))
+    assert float(y) == float(np.float32(1.0) / np.float32(255.0))
+    for x in range(256):
+        q = rn(F(x) * y)
+        r = rn(F(x) - 255 * q)
+        q2 = rn(q + r * y)
+        assert float(q2) == float(np.float32(x) / np.float32(255.0)), x
