@@ -94,14 +94,26 @@ __device__ __forceinline__ void slab_fast(float lx, float ly, float lz, float hx
 //   DEFER  nothing is written; `full` is raised and the traverser gives the ray up, for the caller to re-trace it with an
 //          OVF kernel (one-ray-per-lane grids, which have no bounded set of waves to own overflow regions);
 //   neither: the host has proved from the tree depth that NLDS entries suffice.
+// The two regions are addressed through address-space-qualified pointers so that every access is a plain ds_* or global_*
+// instruction: with generic pointers the compiler merges the two cases of push/pop into one flat access on a selected pointer (slower,
+// and it split the 8-byte pop into two dependent round trips).  An entry travels as one 64-bit word: reference low, entry distance high.
+typedef __attribute__((address_space(3))) unsigned long long LdsWord;
+typedef __attribute__((address_space(1))) unsigned long long GlobalWord;
 template <int NLDS, bool OVF, bool DEFER = false>
 struct LaneStack {
-    uint2* lds;  // this lane's slot of entry 0; entry e is lds[e * 64]
-    uint2* gl;   // OVF only: this lane's slot of overflow entry 0 in global memory; entry e is gl[e * 64]
+    LdsWord* lds;    // this lane's slot of entry 0; entry e is lds[e * 64]
+    GlobalWord* gl;  // OVF only: this lane's slot of overflow entry 0 in global memory; entry e is gl[e * 64]
     int sp;
     bool full;   // DEFER only
+    __device__ __forceinline__ void attach(uint2* lds_lane, uint2* gl_lane) {
+        // a generic pointer into LDS is the aperture base plus the LDS offset: its low 32 bits are the address_space(3) pointer
+        lds = (LdsWord*)(uintptr_t)(uint32_t)(uintptr_t)lds_lane;
+        gl = (GlobalWord*)(uintptr_t)gl_lane;
+        sp = 0;
+        full = false;
+    }
     __device__ __forceinline__ void push(int ref, float tentry) {
-        uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tentry));
+        const unsigned long long e = ((unsigned long long)__float_as_uint(tentry) << 32) | (unsigned long long)(uint32_t)ref;
         if (DEFER) {
             if (sp < NLDS) lds[sp * 64] = e; else full = true;
         } else if (!OVF || sp < NLDS) lds[sp * 64] = e;
@@ -110,8 +122,10 @@ struct LaneStack {
     }
     __device__ __forceinline__ uint2 pop() {
         --sp;
-        if (!OVF || sp < NLDS) return lds[sp * 64];
-        return gl[(sp - NLDS) * 64];
+        unsigned long long e;
+        if (!OVF || sp < NLDS) e = lds[sp * 64];
+        else e = gl[(sp - NLDS) * 64];
+        return make_uint2((uint32_t)e, (uint32_t)(e >> 32));
     }
 };
 // bytes of global overflow space one wave needs (entries NLDS..63 for 64 lanes)
@@ -142,7 +156,7 @@ struct Trav {
 
     __device__ __forceinline__ void reset_counts() { n_nodes = 0; n_tris = 0; }
 
-    __device__ __forceinline__ void attach(uint2* lds_lane, uint2* gl_lane) { st.lds = lds_lane; st.gl = gl_lane; st.sp = 0; st.full = false; }
+    __device__ __forceinline__ void attach(uint2* lds_lane, uint2* gl_lane) { st.attach(lds_lane, gl_lane); }
     // DEFER: the ray ran out of LDS stack and was given up (alive is false, no result): re-trace it with an OVF kernel
     __device__ __forceinline__ bool deferred() const { return DEFER && st.full; }
 
