@@ -73,20 +73,27 @@ __device__ __forceinline__ void slab(float nx, float ny, float nz, float fx, flo
     tentry = tmin;
 }
 
-// The same test for rays whose arithmetic cannot produce a NaN (every 1/dir component finite and non-zero, origin finite; box
+// slab_fast2: the same test for rays whose arithmetic cannot produce a NaN (every 1/dir component finite and non-zero, origin finite; box
 // planes are validated NaN-free at scene creation): with near = min and far = max of the two plane distances per axis, the
 // reference's compare chain reduces to  max3(near) <= min3(far)  (its misses are exactly "some near_i > some far_j", i != j, and
 // near_i <= far_i always), its tmax is min3(far) and its tmin is max3(near) -- the same floats, because min/max return one of
 // their operands.  Rays with a zero, infinite or NaN direction component keep slab(): there 0 * inf = NaN decides the outcome
 // through comparisons that are false, which min/max would not reproduce.
-__device__ __forceinline__ void slab_fast(float lx, float ly, float lz, float hx, float hy, float hz, F3 o, F3 inv, bool& ok, float& tentry) {
-    const float ax = (lx - o.x) * inv.x, bx = (hx - o.x) * inv.x;
-    const float ay = (ly - o.y) * inv.y, by = (hy - o.y) * inv.y;
-    const float az = (lz - o.z) * inv.z, bz = (hz - o.z) * inv.z;
-    const float te = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float tx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    ok = (te <= tx) && (tx > 0.0f);
-    tentry = te;
+// Both children at once, on packed fp32 pairs (v_pk_add_f32 / v_pk_mul_f32: the same IEEE subtract and multiply, two per instruction).
+// Interior record: a = (L.lo.x, L.lo.y, L.hi.x, L.hi.y), b = the same for R, c = (L.lo.z, L.hi.z, R.lo.z, R.hi.z).
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab_fast2(float4 a, float4 b, float4 c, float2v oxy, float2v ixy, float oz, float iz,
+                                           bool& okL, float& teL, bool& okR, float& teR) {
+    const float2v ozz = {oz, oz}, izz = {iz, iz};
+    const float2v l0 = (float2v{a.x, a.y} - oxy) * ixy, l1 = (float2v{a.z, a.w} - oxy) * ixy;
+    const float2v r0 = (float2v{b.x, b.y} - oxy) * ixy, r1 = (float2v{b.z, b.w} - oxy) * ixy;
+    const float2v lz = (float2v{c.x, c.y} - ozz) * izz, rz = (float2v{c.z, c.w} - ozz) * izz;
+    teL = fmaxf(fmaxf(fminf(l0.x, l1.x), fminf(l0.y, l1.y)), fminf(lz.x, lz.y));
+    const float txL = fminf(fminf(fmaxf(l0.x, l1.x), fmaxf(l0.y, l1.y)), fmaxf(lz.x, lz.y));
+    okL = (teL <= txL) && (txL > 0.0f);
+    teR = fmaxf(fmaxf(fminf(r0.x, r1.x), fminf(r0.y, r1.y)), fminf(rz.x, rz.y));
+    const float txR = fminf(fminf(fmaxf(r0.x, r1.x), fmaxf(r0.y, r1.y)), fmaxf(rz.x, rz.y));
+    okR = (teR <= txR) && (txR > 0.0f);
 }
 
 // What happens when a lane needs more than NLDS entries:
@@ -216,11 +223,10 @@ struct Trav {
         if (cur >= 0) {
             bool okL, okR; float teL, teR;
             if (fast) {
-                slab_fast(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, okL, teL);
-                slab_fast(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, okR, teR);
+                slab_fast2(a, b, c, float2v{o.x, o.y}, float2v{inv.x, inv.y}, o.z, inv.z, okL, teL, okR, teR);
             } else {
-                slab(sx ? a.w : a.x, sy ? b.x : a.y, sz ? b.y : a.z, sx ? a.x : a.w, sy ? a.y : b.x, sz ? a.z : b.y, o, inv, okL, teL);
-                slab(sx ? c.y : b.z, sy ? c.z : b.w, sz ? c.w : c.x, sx ? b.z : c.y, sy ? b.w : c.z, sz ? c.x : c.w, o, inv, okR, teR);
+                slab(sx ? a.z : a.x, sy ? a.w : a.y, sz ? c.y : c.x, sx ? a.x : a.z, sy ? a.y : a.w, sz ? c.x : c.y, o, inv, okL, teL);
+                slab(sx ? b.z : b.x, sy ? b.w : b.y, sz ? c.w : c.z, sx ? b.x : b.z, sy ? b.y : b.w, sz ? c.z : c.w, o, inv, okR, teR);
             }
             int refL = __float_as_int(m.x), refR = __float_as_int(m.y);
             bool rightFirst = ((signbits >> __float_as_int(m.z)) & 1u) != 0u;

@@ -309,9 +309,10 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
             const ptgpu_flatnode& L = d->nodes[i + 1];
             const ptgpu_flatnode& R = d->nodes[n.rightChild];
             float4* o = &inner[(size_t)inner_index[i] * 4];
-            o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], L.bmax[0]);
-            o[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
-            o[2] = make_float4(R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
+            // x/y planes pairwise, z planes together: the fast slab test runs on packed fp32 pairs (pt_traverse.hip.h)
+            o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmax[0], L.bmax[1]);
+            o[1] = make_float4(R.bmin[0], R.bmin[1], R.bmax[0], R.bmax[1]);
+            o[2] = make_float4(L.bmin[2], L.bmax[2], R.bmin[2], R.bmax[2]);
             int refL = child_ref(d->nodes, inner_index, i + 1), refR = child_ref(d->nodes, inner_index, n.rightChild);
             float fl, fr, fa;
             int32_t ax = n.axis;

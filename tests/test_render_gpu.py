@@ -119,6 +119,21 @@ def test_nearest_filtering_no_alpha_exact(soup_gpu, textured_soup, oracle):
     _assert_image_exact(g, c, "nearest / no alpha")
 
 
+@pytest.mark.parametrize("bounces", [0, 3, -4])
+def test_bounce_settings_on_open_geometry_exact(soup_gpu, textured_soup, oracle, bounces):
+    """Direct light only / fixed bounces / fixed bounces then roulette on a triangle soup: open geometry gives back-facing hits (the
+    reference flips the normal only when the shadow ray is unoccluded, which decides where the bounce ray starts) and bounce rays
+    that leave the scene inside the fixed-bounce loop (then the roulette section still runs from the last hit point)."""
+    w, h = 80, 64
+    cam, lights = _soup_view(w, h)
+    prm = scene.make_params(width=w, height=h, bounces=bounces, num_aa_rays=2, sobol_block=True, bilinear=True, normal_mapped=True,
+                            termination_prob=0.25, pass_seed=21 + bounces)
+    g = soup_gpu.render_pass(prm, cam, lights)
+    c, _ = oracle.render_pass(textured_soup, prm, cam, lights, nthreads=8)
+    assert c[..., :3].max() > 0.01
+    _assert_image_exact(g, c, "bounces=%d" % bounces)
+
+
 def test_block_subsets_tile_the_image(head_gpu, head, oracle):
     """Image tiles sharded as rank r of N: block_begin = r, block_stride = N; the union equals the full pass bit for bit."""
     w, h = 96, 96
