@@ -579,11 +579,13 @@ static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long l
     trav.alpha_on = ALPHA ? 1 : 0;
     // stack occupancy <= depth - 1 (one far sibling per ancestor level); the counting variant pushes every far child as well
     const int need = s->depth - 1;
-    // LDS stack entries per lane: 24 (13 waves/CU, never overflows up to depth 25) wins while the tree sits in one XCD's L2;
-    // 16 (20 waves/CU, deeper rays deferred) wins once fetches leave L2 -- measured: head 0.153 vs 0.165 ms, 262k-triangle
-    // atrium 1.55 vs 1.33 ms, 10M-triangle cloud 2.96 vs 2.32 ms (closest-hit frames).
+    // LDS stack entries per lane.  24 (13 waves/CU, never overflows up to depth 25) wins while the tree sits in one XCD's L2.  Once
+    // fetches leave L2 more waves win, and rays whose stack outgrows the LDS are deferred: about half the tree depth keeps them rare.
+    // Measured closest / any-hit frames, ms: head (depth 21) 24: 0.147/0.181, 16: 0.154/0.177; 262k-triangle atrium (depth 24)
+    // 8: 1.25/1.66, 12: 1.13/1.71, 16: 1.28/1.90, 24: 1.49/2.24; 10M-triangle cloud (depth 29) 8: 3.77/2.27, 12: 2.54/2.28,
+    // 16: 2.14/2.03, 24: 2.73/2.56.
     const bool small_scene = s->bytes[0] + s->bytes[1] <= (4u << 20) && need <= 24;
-    const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : 16);
+    const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : (need <= 24 ? 12 : 16));
     dim3 grid((unsigned)((n + RC_STEP_BLOCK - 1) / RC_STEP_BLOCK)), block(RC_STEP_BLOCK);
     if constexpr (COUNT || ALPHA) {  // rare variants: one configuration that is valid for every depth
         return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
@@ -606,13 +608,16 @@ static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long l
             }
             hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + 5, 1);
         }
-        if (nlds == 16) {
-            if (defer) hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 16, true>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
-            else hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 16, false>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
-        } else {
-            if (defer) hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 24, true>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
-            else hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, 24, false>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
-        }
+#define PT_RC_STEP(N)                                                                                                                                  \
+    do {                                                                                                                                              \
+        if (defer) hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, N, true>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer); \
+        else hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, N, false>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);      \
+    } while (0)
+        if (nlds == 8) PT_RC_STEP(8);
+        else if (nlds == 12) PT_RC_STEP(12);
+        else if (nlds == 16) PT_RC_STEP(16);
+        else PT_RC_STEP(24);
+#undef PT_RC_STEP
         if (defer) {
             // the number of deferred rays is only known on the device: a small fixed grid, the kernel reads the count itself
             const long long expected = n / 64 < 65536 ? 65536 : n / 64;
