@@ -48,7 +48,7 @@ def main():
     sc.raycast_dev(P(ro), P(rd), n, False, P(rid), None, None, None)
     torch.cuda.synchronize()
     ref_rid = rid.clone()
-    variants = [(1, 24, 0, 1), (1, 16, 0, 1), (2, 24, 32, 1), (2, 16, 32, 1)]
+    variants = [(1, 24, 0, 1), (1, 16, 0, 1), (1, 12, 0, 1), (1, 8, 0, 1), (2, 24, 32, 1)]
     times = {vv: dict(closest=[], anyhit=[], random=[]) for vv in variants}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for r in range(rounds + 1):
