@@ -427,6 +427,7 @@ __global__ __launch_bounds__(RC_STEP_BLOCK) void k_raycast_step(ptd::TravScene S
     __shared__ uint2 lds_stack[RC_STEP_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long i = (long long)blockIdx.x * RC_STEP_BLOCK + threadIdx.x;
+    if (i == 0) atomicAdd(&counters[0], (unsigned long long)n);  // 1 ray = 1 raycast() call (reference src/RayTracer.cpp:192)
     ptd::Trav<ALPHA, COUNT, NLDS, false, DEFER> tr;
     tr.reset_counts();
     tr.attach(&lds_stack[wave][0][lane], nullptr);
@@ -467,6 +468,8 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast_persist(ptd::TravScene S, 
     if (ray_index) {
         const unsigned long long m = counters[5];  // written by an earlier kernel on this stream
         n = (long long)(m < (unsigned long long)n ? m : (unsigned long long)n);
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&counters[0], (unsigned long long)n);  // 1 ray = 1 raycast() call (reference src/RayTracer.cpp:192); deferred rays were counted
     }
     __shared__ uint2 lds_stack[RC_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -523,10 +526,6 @@ __global__ __launch_bounds__(RC_BLOCK) void k_raycast_persist(ptd::TravScene S, 
         atomicAdd(&counters[1], (unsigned long long)tr.n_nodes);
         atomicAdd(&counters[2], (unsigned long long)tr.n_tris);
     }
-}
-
-__global__ void k_add_rays(unsigned long long* counters, unsigned long long n) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counters[0], n);
 }
 
 // Kernel selection.  PTGPU_RAYCAST_IMPL (1 = step-wise, one ray per lane; 2 = persistent step-wise with refill) and
@@ -649,7 +648,6 @@ extern "C" int ptgpu_raycast_batch_dev(ptgpu_scene* s, int use_alpha, const floa
         default: rc = launch_raycast<true, true, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
     }
     if (rc != PTGPU_OK) return rc;
-    hipLaunchKernelGGL(k_add_rays, dim3(1), dim3(64), 0, s->ctx->stream, s->ctx->d_counters, (unsigned long long)n);
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;
 }
