@@ -962,7 +962,9 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     if (!c->d_spill) HIP_TRY(hipMalloc(&c->d_spill, sizeof(float4) * SPILL_CAPACITY));
     const int count = (block_end - block_begin + block_stride - 1) / block_stride;  // blocks of this call
     const long long spb = 1024LL * prm->num_aa_rays;
-    long long batch_samples = (long long)env_int("PTGPU_PT_BATCH_MSAMPLES", 64) << 20;
+    // samples per integrator launch: every launch ends with a tail of waves draining, so few, large launches (the radiance buffer is
+    // 16 B per sample: 4 GiB at 256 Mi, out of 288 GB).  configs[2], ms per pass: 16 Mi 512, 64 Mi 466, 256 Mi 459, 512 Mi 457.
+    long long batch_samples = (long long)env_int("PTGPU_PT_BATCH_MSAMPLES", 256) << 20;
     long long batch_blocks = batch_samples / spb;
     if (batch_blocks < 1) batch_blocks = 1;
     if (batch_blocks > count) batch_blocks = count;
