@@ -193,6 +193,20 @@ int ptgpu_render_pass(ptgpu_scene* scene, const ptgpu_params* params, const ptgp
  * pixels pass through undivided.  Both pointers are DEVICE pointers, [height][width][4] floats. */
 int ptgpu_resolve_dev(ptgpu_context* ctx, const float* d_accum, int32_t width, int32_t height, float* d_out_rgba);
 
+/* Optional device-side BVH builder (no counterpart in the reference, whose builders are the CPU SAH sweep and
+ * median splits of src/Bvh.cpp:98-234, constructed by BVH::BVH(triangles, sahEnabled), src/Bvh.cpp:11-42): a linear BVH over 63-bit
+ * Morton codes, emitted in the reference's FlatNode layout (src/BvhNode.hpp:67-113; pre-order, left child = index + 1, src/Bvh.cpp:70-96)
+ * with subtrees of <= max_tris_in_leaf triangles collapsed to leaves (the reference's maxTrisInLeaf is 3), so ptgpu_scene_create and
+ * every kernel take it like BVH::nodes / BVH::list.  It is NOT the reference's tree: ties between triangles at exactly equal t and the
+ * occluder an any-hit ray reports follow this tree's order, and a ray that grazes a box face within rounding can be culled by one
+ * tree and not by another (the reference's slab test has no padding; measured: 1 of 8.3 M primary rays on a 260 k-triangle scene
+ * with axis-aligned walls, 0 on the other test scenes).  All other closest-hit records are the same floats.
+ * pos: HOST [num_tris][3][3].  out_nodes: HOST, room for 2*num_tris nodes.  out_list: HOST [num_tris].  out_depth: tree height
+ * (ptgpu_scene_create refuses trees deeper than 64; Morton ties are split by position, which can get deep for many coincident
+ * centroids).  Synchronous. */
+int ptgpu_bvh_build_lbvh(ptgpu_context* ctx, const float* pos, int32_t num_tris, int32_t max_tris_in_leaf, ptgpu_flatnode* out_nodes,
+                         int32_t* out_num_nodes, int32_t* out_list, int32_t* out_depth);
+
 /* rtIntersect.inl intersect_triangle1 (src/rtIntersect.inl:215-259; two-sided Moller-Trumbore, EPSILON 1e-9) for n independent
  * (ray, triangle) pairs, HOST pointers: orig/dir/v0/v1/v2 [n][3].  out_hit = 1/0; t,u,v are written as the reference leaves them on a
  * hit and as 0 on a miss.  The reference includes this file but never calls it (its live test is intersect_woop); kept as a separate

@@ -97,6 +97,7 @@ SIGNATURES = [
     ("ptgpu_render_pass", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("ptgpu_resolve_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     ("ptgpu_intersect_triangle1_batch", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
+    ("ptgpu_bvh_build_lbvh", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
 ]
 
 _lib = None
@@ -206,6 +207,18 @@ class Context:
         _check(self.lib.ptgpu_intersect_triangle1_batch(self.handle, *(x.ctypes.data for x in a), n, hit.ctypes.data, t.ctypes.data,
                                                         u.ctypes.data, v.ctypes.data))
         return hit, t, u, v
+
+    def bvh_build_lbvh(self, pos, max_tris_in_leaf=3):
+        """Device-side linear BVH over triangle positions [n,3,3] -> (nodes FLATNODE_DTYPE[num_nodes], list int32[n], depth), in the
+        reference's layout (feed them to Scene like a tree from the CPU builders)."""
+        pos = _f32(pos).reshape(-1, 3, 3)
+        n = pos.shape[0]
+        nodes = np.zeros(max(2 * n, 1), dtype=FLATNODE_DTYPE)
+        lst = np.zeros(max(n, 1), dtype=np.int32)
+        num, depth = C.c_int32(0), C.c_int32(0)
+        _check(self.lib.ptgpu_bvh_build_lbvh(self.handle, pos.ctypes.data, n, max_tris_in_leaf, nodes.ctypes.data, C.byref(num), lst.ctypes.data,
+                                             C.byref(depth)))
+        return nodes[: num.value].copy(), lst[:n].copy(), depth.value
 
     def gen_primary_dev(self, cam, width, height, d_orig, d_dir):
         _check(self.lib.ptgpu_gen_primary_dev(self.handle, C.byref(cam), width, height, d_orig, d_dir))

@@ -12,6 +12,7 @@
 #include "../../include/ptgpu.h"
 #include "pt_traverse.hip.h"
 #include "pt_integrator.hip.h"
+#include "pt_lbvh.hip.h"
 
 namespace ptd {
 __device__ const uint32_t g_sobol_matrices[1024 * 52] = {
@@ -1114,5 +1115,106 @@ extern "C" int ptgpu_intersect_triangle1_batch(ptgpu_context* c, const float* or
     if (d_in) hipFree(d_in);
     if (d_out) hipFree(d_out);
     if (e != hipSuccess) return fail(PTGPU_E_HIP, "intersect_triangle1 batch: %s", hipGetErrorString(e));
+    return PTGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side BVH builder (pt_lbvh.hip.h): host arrays in, reference-layout tree out
+// ------------------------------------------------------------------------------------------------
+extern "C" int ptgpu_bvh_build_lbvh(ptgpu_context* c, const float* pos, int32_t num_tris, int32_t max_tris_in_leaf, ptgpu_flatnode* out_nodes,
+                                    int32_t* out_num_nodes, int32_t* out_list, int32_t* out_depth) {
+    if (!c || !out_num_nodes) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (num_tris < 0) return fail(PTGPU_E_INVALID, "num_tris < 0");
+    if (max_tris_in_leaf < 1) return fail(PTGPU_E_INVALID, "max_tris_in_leaf %d < 1", max_tris_in_leaf);
+    if (num_tris > 0 && (!pos || !out_nodes || !out_list)) return fail(PTGPU_E_INVALID, "NULL array");
+    *out_num_nodes = 0;
+    if (out_depth) *out_depth = 0;
+    if (num_tris == 0) return PTGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = num_tris;
+    hipStream_t st = c->stream;
+    // everything in one allocation list so that every exit path frees it
+    std::vector<void*> owned;
+    auto cleanup = [&]() { for (void* p : owned) hipFree(p); };
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
+        owned.push_back(p);
+        return p;
+    };
+#define LB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(PTGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+#define LB_ALLOC(var, type, count) type* var = (type*)dalloc((size_t)(count) * sizeof(type)); if (!var) { cleanup(); return fail(PTGPU_E_HIP, "hipMalloc failed in the BVH builder"); }
+    const int n_int = n - 1;
+    LB_ALLOC(d_pos, float, (size_t)n * 9)
+    LB_ALLOC(d_lo, float4, n)
+    LB_ALLOC(d_hi, float4, n)
+    LB_ALLOC(d_bounds, uint32_t, 8)
+    LB_ALLOC(d_keys, unsigned long long, n)
+    LB_ALLOC(d_keys2, unsigned long long, n)
+    LB_ALLOC(d_vals, int32_t, n)
+    LB_ALLOC(d_vals2, int32_t, n)
+    LB_ALLOC(d_out, int32_t, 4)
+    const uint32_t h_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    LB_TRY(hipMemcpyAsync(d_pos, pos, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, st));
+    LB_TRY(hipMemcpyAsync(d_bounds, h_bounds, sizeof h_bounds, hipMemcpyHostToDevice, st));
+    LB_TRY(hipMemsetAsync(d_out, 0, 4 * sizeof(int32_t), st));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(ptl::k_lbvh_prims, dim3(blocks), dim3(256), 0, st, d_pos, n, d_lo, d_hi, d_bounds);
+    hipLaunchKernelGGL(ptl::k_lbvh_morton, dim3(blocks), dim3(256), 0, st, d_lo, d_hi, n, d_bounds, d_keys, d_vals);
+    size_t temp_bytes = 0;
+    LB_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0u, 63u, st));
+    LB_ALLOC(d_temp, char, temp_bytes)
+    LB_TRY(rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0u, 63u, st));
+    uint32_t hb[8];
+    LB_TRY(hipMemcpyAsync(hb, d_bounds, sizeof hb, hipMemcpyDeviceToHost, st));
+    LB_TRY(hipStreamSynchronize(st));
+    if (hb[6]) { cleanup(); return fail(PTGPU_E_INVALID, "a triangle has a vertex that is not finite"); }
+    LB_TRY(hipMemcpyAsync(out_list, d_vals2, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (n == 1) {
+        LB_TRY(hipStreamSynchronize(st));
+        ptgpu_flatnode f;
+        memset(&f, 0, sizeof f);
+        float mn[3], mx[3];
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(pos[k], std::min(pos[3 + k], pos[6 + k]));
+            mx[k] = std::max(pos[k], std::max(pos[3 + k], pos[6 + k]));
+            f.bmin[k] = mn[k]; f.bmax[k] = mx[k];
+        }
+        f.leaf = 1; f.triangles = 1;
+        out_nodes[0] = f;
+        *out_num_nodes = 1;
+        if (out_depth) *out_depth = 1;
+        cleanup();
+        return PTGPU_OK;
+    }
+    LB_ALLOC(d_child, int2, n_int)
+    LB_ALLOC(d_range, int2, n_int)
+    LB_ALLOC(d_parent, int32_t, n_int)
+    LB_ALLOC(d_leaf_parent, int32_t, n)
+    LB_ALLOC(d_box_lo, float4, n_int)
+    LB_ALLOC(d_box_hi, float4, n_int)
+    LB_ALLOC(d_size, int32_t, n_int)
+    LB_ALLOC(d_arrived, uint32_t, n_int)
+    LB_ALLOC(d_nodes, ptgpu_flatnode, (size_t)2 * n)
+    LB_TRY(hipMemsetAsync(d_arrived, 0, (size_t)n_int * sizeof(uint32_t), st));
+    ptl::Tree T;
+    T.n = n; T.keys = d_keys2; T.child = d_child; T.range = d_range; T.parent = d_parent; T.leaf_parent = d_leaf_parent;
+    T.box_lo = d_box_lo; T.box_hi = d_box_hi; T.size = d_size; T.arrived = d_arrived;
+    hipLaunchKernelGGL(ptl::k_lbvh_hierarchy, dim3((unsigned)((n_int + 255) / 256)), dim3(256), 0, st, T);
+    hipLaunchKernelGGL(ptl::k_lbvh_fit, dim3(blocks), dim3(256), 0, st, T, d_vals2, d_lo, d_hi, (int)max_tris_in_leaf);
+    hipLaunchKernelGGL(ptl::k_lbvh_emit, dim3((unsigned)(((size_t)n_int + n + 255) / 256)), dim3(256), 0, st, T, d_vals2, d_lo, d_hi, (int)max_tris_in_leaf,
+                       d_nodes, d_out);
+    LB_TRY(hipGetLastError());
+    int32_t h_size = 0, h_out[4];
+    LB_TRY(hipMemcpyAsync(&h_size, d_size, sizeof(int32_t), hipMemcpyDeviceToHost, st));  // size of the root's subtree
+    LB_TRY(hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, st));
+    LB_TRY(hipStreamSynchronize(st));
+    if (h_size < 1 || h_size > 2 * n) { cleanup(); return fail(PTGPU_E_HIP, "BVH builder produced %d nodes for %d triangles", h_size, n); }
+    LB_TRY(hipMemcpy(out_nodes, d_nodes, (size_t)h_size * sizeof(ptgpu_flatnode), hipMemcpyDeviceToHost));
+    *out_num_nodes = h_size;
+    if (out_depth) *out_depth = h_out[0];
+    cleanup();
+#undef LB_TRY
+#undef LB_ALLOC
     return PTGPU_OK;
 }

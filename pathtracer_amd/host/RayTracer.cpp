@@ -43,6 +43,29 @@ void RayTracer::constructHierarchy(std::vector<RTTriangle>& triangles, bool sahE
     invalidateDeviceScene();
 }
 
+void RayTracer::constructHierarchyOnDevice(std::vector<RTTriangle>& triangles, int maxTrisInLeaf) {
+    m_triangles = &triangles;
+    const size_t n = triangles.size();
+    std::vector<float> pos(n * 9);
+    for (size_t i = 0; i < n; ++i)
+        for (int v = 0; v < 3; ++v) {
+            const Vec3f& p = triangles[i].m_vertices[v].p;
+            pos[i * 9 + v * 3 + 0] = p.x; pos[i * 9 + v * 3 + 1] = p.y; pos[i * 9 + v * 3 + 2] = p.z;
+        }
+    static_assert(sizeof(FlatNode) == sizeof(ptgpu_flatnode), "FlatNode is uploaded and downloaded as ptgpu_flatnode");
+    std::vector<FlatNode> nodes(std::max<size_t>(2 * n, 1));
+    std::vector<int32_t> list(std::max<size_t>(n, 1));
+    int32_t numNodes = 0, height = 0;
+    PT_GPU(ptgpu_bvh_build_lbvh(GpuDevice::instance().ctx(), pos.data(), (int32_t)n, maxTrisInLeaf,
+                                reinterpret_cast<ptgpu_flatnode*>(nodes.data()), &numNodes, list.data(), &height));
+    nodes.resize((size_t)numNodes);
+    list.resize(n);
+    int32_t splits = 0;  // BVH::depth counts splits, like the reference's field
+    for (const FlatNode& f : nodes) splits += f.leaf ? 0 : 1;
+    bvh = BVH(m_triangles, std::move(list), std::move(nodes), splits);
+    invalidateDeviceScene();
+}
+
 // Cache file layout (reference src/RayTracer.cpp:139-165): int32 listSize, int32 list[], int32 nNodes, then per node
 // min(3f) max(3f) startIdx endIdx rightChild, leaf as ONE byte, axis; finally int32 depth.
 namespace {

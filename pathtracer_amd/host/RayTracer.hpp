@@ -30,6 +30,9 @@ public:
     void raycastBatch(const Vec3f* orig, const Vec3f* dir, size_t n, bool occlusion, RaycastResult* out) const;
 
     void constructHierarchy(std::vector<RTTriangle>& triangles, bool sahEnabled);
+    // Not in the reference: the linear BVH built on the device (ptgpu_bvh_build_lbvh), installed as bvh.nodes / bvh.list like a tree
+    // from the CPU builders.  Hit records can differ from the SAH tree's at exact ties (see include/ptgpu.h).
+    void constructHierarchyOnDevice(std::vector<RTTriangle>& triangles, int maxTrisInLeaf = 3);
     void loadHierarchy(const char* filename, std::vector<RTTriangle>& triangles);
     void saveHierarchy(const char* filename, const std::vector<RTTriangle>& triangles);
 

@@ -2,7 +2,7 @@
 // App::handleEvent do (reference src/App.cpp:146-239, 457-489, 754-908) without the window: load a mesh, build (or load the
 // cached) hierarchy, render N passes with PathTraceRenderer on the MI355X, write the picture, print the reference's statistics.
 //
-//   ptrender <mesh.ptmesh|mesh.obj> [-builder sah|object_median|spatial_median] [-spp N] [-passes N] [-size WxH]
+//   ptrender <mesh.ptmesh|mesh.obj> [-builder sah|object_median|spatial_median|lbvh] [-spp N] [-passes N] [-size WxH]
 //            [-bounces N] [-rr] [-aa sobol|gauss] [-filter W] [-normal_maps] [-dof APERTURE FOCAL] [-whitted] [-light_size S] [-emission E]
 //            [-bat_render] [-output_images] [-o out.ppm] [-cache DIR] [-ranks N -rank R]
 //
@@ -24,19 +24,19 @@ static bool fileExists(const std::string& f) { return std::ifstream(f).good(); }
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: ptrender <mesh> [-builder sah|object_median|spatial_median] [-spp N] [-passes N] [-size WxH] [-bounces N] [-rr]\n"
+        std::fprintf(stderr, "usage: ptrender <mesh> [-builder sah|object_median|spatial_median|lbvh] [-spp N] [-passes N] [-size WxH] [-bounces N] [-rr]\n"
                              "       [-aa sobol|gauss] [-filter W] [-normal_maps] [-dof APERTURE FOCAL] [-light_size S] [-bat_render] [-output_images]\n"
                              "       [-o out.ppm] [-cache DIR] [-ranks N -rank R]\n");
         return 2;
     }
     std::string meshPath = argv[1], outPath, cacheDir = ".";
-    bool sah = true, batch = false, outputImages = false, rr = false, sobolAA = true, normalMaps = false, dof = false, whitted = false;
+    bool sah = true, lbvh = false, batch = false, outputImages = false, rr = false, sobolAA = true, normalMaps = false, dof = false, whitted = false;
     int spp = 4, passes = 1, width = 512, height = 512, bounces = 1, ranks = 1, rank = 0;
     float filterWidth = 1.0f, aperture = 0.0001f, focal = 0.1f, lightSize = 0.25f, emission = 100.0f;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", a.c_str()); std::exit(2); } return argv[++i]; };
-        if (a == "-builder") { std::string b = next(); sah = (b == "sah"); if (b != "sah" && b != "object_median" && b != "spatial_median" && b != "none" && b != "linear") std::printf("BVH builder not recognized, using Surface Area Heuristic\n"), sah = true; }
+        if (a == "-builder") { std::string b = next(); sah = (b == "sah"); lbvh = (b == "lbvh"); if (b != "sah" && b != "lbvh" && b != "object_median" && b != "spatial_median" && b != "none" && b != "linear") std::printf("BVH builder not recognized, using Surface Area Heuristic\n"), sah = true; }
         else if (a == "-spp") spp = std::atoi(next().c_str());
         else if (a == "-passes") passes = std::atoi(next().c_str());
         else if (a == "-size") { std::string s = next(); if (std::sscanf(s.c_str(), "%dx%d", &width, &height) != 2) { std::fprintf(stderr, "-size WxH\n"); return 2; } }
@@ -80,13 +80,14 @@ int main(int argc, char** argv) {
         std::string md5 = RayTracer::computeMD5(positions);
         std::printf("Mesh MD5: %s\n", md5.c_str());
         RayTracer rt;
-        std::string cacheFile = cacheDir + "/Hierarchy-" + md5 + (sah ? "-sah" : "") + "-x64.bin";
+        std::string cacheFile = cacheDir + "/Hierarchy-" + md5 + (sah ? "-sah" : (lbvh ? "-lbvh" : "")) + "-x64.bin";
         if (!batch && fileExists(cacheFile)) {
             rt.loadHierarchy(cacheFile.c_str(), tris);
             std::printf("Loaded hierarchy from %s\n\n", cacheFile.c_str());
         } else {
             auto t0 = std::chrono::steady_clock::now();
-            rt.constructHierarchy(tris, sah);
+            if (lbvh) rt.constructHierarchyOnDevice(tris);  // device-side linear BVH (not in the reference)
+            else rt.constructHierarchy(tris, sah);
             int ms = (int)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
             std::printf("Build time: %d ms\n", ms);
             if (!batch) { rt.saveHierarchy(cacheFile.c_str(), tris); std::printf("Saved hierarchy to %s\n", cacheFile.c_str()); }

@@ -82,3 +82,32 @@ def test_host_path_trace_renderer_matches_oracle(host_rt, head, oracle):
     assert np.array_equal(accum.view(np.uint32), c.view(np.uint32))
     assert np.array_equal(resolved.view(np.uint32), oracle.resolve(c, libm=False).view(np.uint32))
     assert rays == total
+
+
+def test_host_device_built_hierarchy(head, oracle, tmp_path):
+    """RayTracer::constructHierarchyOnDevice (device-side linear BVH, not in the reference): the installed nodes / list trace exactly
+    like the oracle on the same tree, survive the hierarchy cache file, and give the SAH tree's closest distances."""
+    rt = hostapi.HostRayTracer(scene.HEAD_MESH, sah=True)
+    try:
+        rt.construct_hierarchy_on_device(3)
+        nodes, lst = rt.bvh()
+        assert rt.num_nodes == nodes.shape[0] and sorted(lst.tolist()) == list(range(17692))
+        assert rt.depth_field == int((nodes["leaf"] == 0).sum())  # BVH::depth counts splits
+        sd = dict(head["sd"])
+        sd["nodes"], sd["list"] = nodes, lst
+        cam = scene.make_camera(width=200, height=120)
+        o, d = oracle.gen_primary(cam, 200, 120)
+        for occ in (False, True):
+            g, c = rt.raycast(o, d, occ), oracle.raycast(sd, o, d, occ)
+            assert np.array_equal(g["id"], c["id"]) and np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+        ref = oracle.raycast(head["sd"], o, d, False)
+        assert np.array_equal(rt.raycast(o, d, False)["t"].view(np.uint32), ref["t"].view(np.uint32))
+        path = str(tmp_path / "Hierarchy-lbvh.bin")
+        rt.save_hierarchy(path)
+        rt.load_hierarchy(path)
+        n2, l2 = rt.bvh()
+        for f in ("bmin", "bmax", "startIdx", "endIdx", "rightChild", "leaf", "axis"):
+            assert np.array_equal(n2[f], nodes[f]), f
+        assert np.array_equal(l2, lst)
+    finally:
+        rt.close()
