@@ -258,7 +258,8 @@ struct PathState {
 template <bool COUNT, int NLDS, bool OVF, int BLOCK>
 __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene& SS, const ptgpu_params& prm, const ptgpu_camera& cam,
                                           const ptgpu_light* __restrict__ lights, const PassDesc& pd, float4* __restrict__ rad,
-                                          unsigned long long* counters, uint2* lds_lane, uint2* gl_lane, int service_threshold) {
+                                          unsigned long long* counters, uint2* lds_lane, uint2* gl_lane, int service_threshold_packed) {
+    const int service_threshold = service_threshold_packed & 0xff, control_min = (service_threshold_packed >> 8) & 0xff;
     const int lane = threadIdx.x & 63;
     Trav<true, COUNT, NLDS, OVF> tr;
     tr.reset_counts();
@@ -336,13 +337,15 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
     // back-facing hit only inside its "unoccluded" branch (:346-353), and the bounce leaves along the normal; for a back-facing,
     // unoccluded hit the pending bounce (built from the unflipped normal) is discarded and the lane asks for a new one (ST_REBOUNCE).
     // The wave runs the block most lanes wait for once that count reaches service_threshold (or exceeds the traversing lanes), so each
-    // block runs with many of its lanes; otherwise all traversing lanes take one step.  Classification is redone only when a ray has
-    // finished or a block has run.
+    // block runs with many of its lanes; otherwise all traversing lanes take one step.  The control section (settling finished rays,
+    // classification) is entered only after a block has run or once control_min more rays have finished (or none is left running):
+    // entering it for every single finished ray cost more instructions than the idle lanes it saved (16: -5.5 % per pass).
     bool dirty = true;
     unsigned long long prev_alive = 0ull;
     for (;;) {
         unsigned long long alive_mask = __ballot(tr.alive);
-        if (dirty || alive_mask != prev_alive) {
+        const int newly_done = __popcll(prev_alive & ~alive_mask);
+        if (dirty || newly_done >= control_min || (newly_done > 0 && alive_mask == 0ull)) {
             PT_STAMP_BEGIN();
             dirty = false;
             if (!tr.alive && ps.stage == ST_SH && ps.mode != 3) {

@@ -935,7 +935,7 @@ static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const pt
         if (rc != PTGPU_OK) return rc;
     }
     hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
-                       c->d_counters, env_int("PTGPU_PT_SERVICE", 32), c->d_stack_ovf);
+                       c->d_counters, env_int("PTGPU_PT_SERVICE", 32) | (env_int("PTGPU_PT_CTLMIN", 16) << 8), c->d_stack_ovf);
     return PTGPU_OK;
 }
 
