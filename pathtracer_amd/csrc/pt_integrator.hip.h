@@ -249,7 +249,7 @@ struct PathState {
     uint32_t bits;  // pending bounce ray: Trav::Prepared::bits | PB_*
     float gloss, normalization, terminate, aux;  // aux: 4th output word (local pixel bits or Gaussian weight)
     int li, bounce, base, mode, stage;
-    long long sid;
+    int sid;  // padded sample id inside this launch
     Rng R;
 };
 
@@ -270,10 +270,12 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
     ps.sid = -1;
     uint32_t n_rays = 0;
 
-    const long long total = (long long)pd.num_blocks * pd.samples_per_block;
-    const long long total_waves = (long long)gridDim.x * (BLOCK / 64);
-    const long long wave_id = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    long long next = 0, end = 0, round = -1;
+    // Sample ids of one launch fit 31 bits (the host caps a batch at 2^30).  The chunk cursor is wave-uniform: readfirstlane keeps it in
+    // scalar registers (as 64-bit per-lane values it cost 8 VGPRs for the whole life of the kernel).
+    const uint32_t total = (uint32_t)pd.num_blocks * (uint32_t)pd.samples_per_block;
+    const uint32_t total_waves = gridDim.x * (BLOCK / 64);
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+    uint32_t next = 0, end = 0, round = 0xffffffffu;
     bool exhausted = false;
     const int bounces = prm.bounces < 0 ? -prm.bounces : prm.bounces;
     const float div_x = 1.0f / (float)prm.width, div_y = 1.0f / (float)prm.height;
@@ -508,18 +510,20 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                 unsigned long long need = __ballot(ps.stage == ST_IDLE);
                 while (need != 0ull && !exhausted) {
                     if (next >= end) {
-                        round += 1;
-                        const long long cbase = (round * total_waves + (wave_id + round * 997) % total_waves) * 64;
-                        if (cbase >= total) { exhausted = true; break; }
-                        next = cbase;
-                        end = next + 64 < total ? next + 64 : total;
+                        // round r hands this wave chunk r*W + (w + 997 r) mod W: rotating the assignment every round keeps one wave
+                        // from drawing the same image region (all cheap or all expensive) in every round
+                        round = __builtin_amdgcn_readfirstlane(round + 1u);
+                        const unsigned long long cbase = ((unsigned long long)round * total_waves + (wave_id + (round % total_waves) * 997u) % total_waves) * 64ull;
+                        if (cbase >= (unsigned long long)total) { exhausted = true; break; }
+                        next = __builtin_amdgcn_readfirstlane((uint32_t)cbase);
+                        end = next + 64u < total ? next + 64u : total;
                     }
                     const int avail = (int)(end - next);
                     const int rank = __popcll(need & ((1ull << lane) - 1ull));
                     if (ps.stage == ST_IDLE && rank < avail) {
-                        const long long sid = next + rank;
-                        const int jj = (int)(sid / pd.samples_per_block);
-                        const int s = (int)(sid - (long long)jj * pd.samples_per_block);
+                        const int sid = (int)(next + (uint32_t)rank);
+                        const int jj = (int)((uint32_t)sid / (uint32_t)pd.samples_per_block);
+                        const int s = sid - jj * pd.samples_per_block;
                         const int idx = pd.block_begin + (pd.j0 + jj) * pd.block_stride;
                         const int bx = (idx % pd.blocks_x) * 32, by = (idx / pd.blocks_x) * 32;
                         const int bw = (bx + 32 < prm.width) ? 32 : prm.width - bx;
@@ -597,7 +601,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         }
                     }
                     const int n_need = __popcll(need);
-                    next += n_need < avail ? n_need : avail;
+                    next = __builtin_amdgcn_readfirstlane(next + (uint32_t)(n_need < avail ? n_need : avail));
                     need = __ballot(ps.stage == ST_IDLE);
                 }
                 if (ps.sid == -2) { ps.stage = ST_IDLE; ps.sid = -1; }  // padded sample id: nothing to trace

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <vector>
 
 #include "../../include/ptgpu.h"
@@ -555,11 +556,13 @@ static int launch_rc_persist(ptgpu_scene* s, const ptd::TravScene& trav, const f
     if (want < 1) want = 1;
     long long blocks = (want + (RC_BLOCK / 64) - 1) / (RC_BLOCK / 64);
     // a small multiple of the blocks resident at once (LDS-limited): long-lived waves, dispatcher-level balancing
-    static int per_cu = 0;
+    static std::atomic<int> per_cu_cache{0};  // same value whichever thread computes it first
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int v = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>, RC_BLOCK, 0) != hipSuccess || v < 1) v = 1;
         per_cu = v;
+        per_cu_cache.store(v, std::memory_order_relaxed);
     }
     long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_RAYCAST_OVERSUB", 1);
     if (blocks > resident) blocks = resident;
@@ -778,7 +781,12 @@ constexpr int PT_BLOCK = PT_BLOCK_THREADS;
 #endif
 
 template <bool COUNT, int NLDS, bool OVF>
-__global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void k_integrate(ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
+#ifdef PT_NUM_VGPR
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(PT_NUM_VGPR, PT_NUM_VGPR))) void k_integrate(
+#else
+__global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void k_integrate(
+#endif
+ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
                                                         const ptgpu_light* __restrict__ lights, ptd::PassDesc pd, float4* __restrict__ rad,
                                                         unsigned long long* counters, int service_threshold, uint2* stack_ovf) {
     __shared__ uint2 lds_stack[PT_BLOCK / 64][NLDS][64];
@@ -920,11 +928,13 @@ template <bool COUNT, int NLDS, bool OVF>
 static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const ptd::ShadeScene& ss, const ptgpu_params* prm, const ptgpu_camera* cam,
                             const ptd::PassDesc& pd) {
     ptgpu_context* c = s->ctx;
-    static int per_cu = 0;
+    static std::atomic<int> per_cu_cache{0};  // same value whichever thread computes it first
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int v = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_integrate<COUNT, NLDS, OVF>, PT_BLOCK, 0) != hipSuccess || v < 1) v = 1;
         per_cu = v;
+        per_cu_cache.store(v, std::memory_order_relaxed);
     }
     const long long total = (long long)pd.num_blocks * pd.samples_per_block;
     long long blocks = (total + PT_BLOCK - 1) / PT_BLOCK;
@@ -934,7 +944,7 @@ static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const pt
         int rc = ensure_stack_overflow(c, (size_t)blocks * (PT_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
         if (rc != PTGPU_OK) return rc;
     }
-    hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
+    hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), (size_t)env_int("PTGPU_PT_EXTRA_LDS", 0), c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
                        c->d_counters, env_int("PTGPU_PT_SERVICE", 32) | (env_int("PTGPU_PT_CTLMIN", 16) << 8), c->d_stack_ovf);
     return PTGPU_OK;
 }
@@ -966,6 +976,8 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     // samples per integrator launch: every launch ends with a tail of waves draining, so few, large launches (the radiance buffer is
     // 16 B per sample: 4 GiB at 256 Mi, out of 288 GB).  configs[2], ms per pass: 16 Mi 512, 64 Mi 466, 256 Mi 459, 512 Mi 457.
     long long batch_samples = (long long)env_int("PTGPU_PT_BATCH_MSAMPLES", 256) << 20;
+    if (batch_samples > (1LL << 30)) batch_samples = 1LL << 30;  // sample ids of one launch are 31-bit in the kernels
+    if (spb > (1LL << 30)) return fail(PTGPU_E_UNSUPPORTED, "num_aa_rays %d: more than 2^30 samples per block", prm->num_aa_rays);
     long long batch_blocks = batch_samples / spb;
     if (batch_blocks < 1) batch_blocks = 1;
     if (batch_blocks > count) batch_blocks = count;
@@ -989,6 +1001,7 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
         pd.blocks_x = blocks_x; pd.samples_per_block = (int32_t)spb; pd.num_lights = num_lights;
         pd.inv_prob = 1.0f / prm->termination_prob;
         if (c->count) rc = launch_integrate<true, 16, true>(s, trav, ss, prm, cam, pd);
+        else if (nlds == 12) rc = launch_integrate<false, 12, true>(s, trav, ss, prm, cam, pd);
         else if (stack_need > 24 || (stack_need > 16 && nlds == 16)) rc = launch_integrate<false, 16, true>(s, trav, ss, prm, cam, pd);
         else if (nlds == 16) rc = launch_integrate<false, 16, false>(s, trav, ss, prm, cam, pd);
         else rc = launch_integrate<false, 24, false>(s, trav, ss, prm, cam, pd);
