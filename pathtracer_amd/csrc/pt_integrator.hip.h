@@ -243,12 +243,13 @@ enum : int { ST_IDLE = 0, ST_EXT = 1, ST_SH = 2, ST_BOUNCE = 3, ST_WSHADOW = 4, 
 enum : uint32_t { PB_PENDING = 64u, PB_BACKFACING = 128u };  // above Trav::Prepared's bits
 
 struct PathState {
-    F3 O, N, V, diffuse, throughput, Ei, emission;
+    F3 O, N, V, diffuse, throughput, Ei;
     F3 c;      // path tracing: radiance this hit adds if its shadow ray is unoccluded; Whitted: the specular colour
     F3 inv_n;  // pending bounce ray: reciprocal direction
     uint32_t bits;  // pending bounce ray: Trav::Prepared::bits | PB_*
-    float gloss, normalization, terminate, aux;  // aux: 4th output word (local pixel bits or Gaussian weight)
-    int li, bounce, base, mode, stage;
+    float gloss, normalization, aux;  // aux: 4th output word (local pixel bits or Gaussian weight)
+    int li0;  // path tracing: the light chosen at the path's FIRST hit, whose emission every later hit uses (:341); Whitted: this hit's light
+    int bounce, base, mode, stage;
     int sid;  // padded sample id inside this launch
     Rng R;
 };
@@ -291,16 +292,16 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
     };
     // loop control of tracePath between two rays: 1 = fixed-bounce loop test (:389), 2 = roulette entry (:466-468),
     // 3 = roulette loop test (:471).  Leaves the lane asking for a bounce ray (ST_BOUNCE) or at the end of its path (ST_FIN).
-    auto advance = [&](int next_ctl) {
+    auto advance = [&](int next_ctl, float terminate) {
         if (next_ctl == 1) {
             if (ps.bounce < bounces) { ps.mode = 1; ps.stage = ST_BOUNCE; return; }
             next_ctl = 2;
         }
         if (next_ctl == 2) {
-            if (prm.bounces < 0) { ps.terminate = ps.R.getF32(0.0f, 1.0f); next_ctl = 3; }
+            if (prm.bounces < 0) { terminate = ps.R.getF32(0.0f, 1.0f); next_ctl = 3; }
             else { ps.stage = ST_FIN; return; }
         }
-        if (ps.terminate > prm.termination_prob) { ps.mode = 2; ps.stage = ST_BOUNCE; }
+        if (terminate > prm.termination_prob) { ps.mode = 2; ps.stage = ST_BOUNCE; }
         else ps.stage = ST_FIN;
     };
 
@@ -310,7 +311,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
     // Whitted: next disk sample of the chosen light and its shadow ray (shared tail of the hit and shade blocks)
     auto whitted_shadow = [&]() {
         // AreaLight::sampleDisk, src/AreaLight.cpp:87-108, with dimension 0
-        const ptgpu_light& Lt = lights[ps.li];
+        const ptgpu_light& Lt = lights[ps.li0];
         int r = ps.R.getS32(1, 1000);
         float sa, sb;
         sobol32x2(SS.sobol_pairs, (uint32_t)(ps.base + r), 4u, sa, sb);
@@ -370,7 +371,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
             // closest-hit ray that missed (after the section above: a bounce ray launched there may miss the scene's box at once)
             if (!tr.alive && ps.stage == ST_EXT && tr.pmin < 0) {
                 if (ps.mode == 1) {  // inside the fixed-bounce loop: `break`, then the roulette section
-                    advance(2);
+                    advance(2, 0.0f);
                     if (ps.stage == ST_FIN) finish();
                 } else finish();     // primary miss (Ei = 0), or miss inside the roulette loop
             }
@@ -404,14 +405,15 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                     ps.O = tr.o + tr.tmin * tr.d;
                     F3 specular;
                     get_texture_parameters(SS, prm, hit_tri, hit_mat, tr.umin, tr.vmin, ps.diffuse, ps.N, specular);
-                    ps.li = get_light_to_sample(ps.O, lights, pd.num_lights, ps.R);
+                    const int li = get_light_to_sample(ps.O, lights, pd.num_lights, ps.R);
+                    if (first || prm.whitted) ps.li0 = li;
                     if (prm.whitted) {
                         ps.c = specular;
-                        ps.terminate = 0.0f;  // "shadow": number of unoccluded light rays; ps.bounce = light-ray index
+                        ps.inv_n.x = 0.0f;  // "shadow": number of unoccluded light rays (inv_n is otherwise unused here); ps.bounce = light-ray index
                         ps.mode = 3;
                         ps.stage = ST_WSHADOW;
                     } else {
-                        const ptgpu_light& Lt = lights[ps.li];
+                        const ptgpu_light& Lt = lights[li];
                         // AreaLight::sample, src/AreaLight.cpp:69-85
                         int dim = 4 + 4 * sobol_bounce_dim(ps.bounce);
                         int r = ps.R.getS32(1, 10000);
@@ -422,7 +424,8 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         F3 Pl = light_col(Lt, 3) + light_col(Lt, 0) * lx + light_col(Lt, 1) * ly;
                         const float pdf = 1.0f / (4.0f * Lt.size[0] * Lt.size[1]);
                         const F3 L = Pl - ps.O;
-                        if (first) ps.emission = f3(Lt.E[0], Lt.E[1], Lt.E[2]) * prm.intensity;  // once per path (:341)
+                        const ptgpu_light& L0 = lights[ps.li0];
+                        const F3 emission = f3(L0.E[0], L0.E[1], L0.E[2]) * prm.intensity;  // set once per path in the reference (:341)
                         tr.begin(TS, ps.O + 0.0001f * ps.N, L, true);
                         n_rays += 1;
                         // what the light adds if the shadow ray finds nothing: reference :346-376 / :416-450 / :500-534
@@ -440,14 +443,14 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                             F3 color = ps.diffuse;
                             color = color + specular * ptm_pow(sel_max(0.0f, dot(Nf, H)), ps.gloss) * ps.normalization;
                             const float invPi = 0.31830988618379f;
-                            if (ps.mode == 0) ps.c = color * invPi * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
-                            else if (ps.mode == 1) ps.c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
-                            else ps.c = color * invPi * ps.throughput * ps.emission * cos_theta * cos_theta_l * inv_d * inv_pdf * pd.inv_prob;
+                            if (ps.mode == 0) ps.c = color * invPi * emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
+                            else if (ps.mode == 1) ps.c = color * invPi * ps.throughput * emission * cos_theta * cos_theta_l * inv_d * inv_pdf;
+                            else ps.c = color * invPi * ps.throughput * emission * cos_theta * cos_theta_l * inv_d * inv_pdf * pd.inv_prob;
                             ps.bits = back ? PB_BACKFACING : 0u;
                         }
                         // loop control after the shade (random draws in the reference's order)
-                        if (ps.mode == 2) { ps.terminate = ps.R.getF32(0.0f, 1.0f); ps.bounce += 1; advance(3); }
-                        else { if (ps.mode == 1) ps.bounce += 1; advance(1); }
+                        if (ps.mode == 2) { const float terminate = ps.R.getF32(0.0f, 1.0f); ps.bounce += 1; advance(3, terminate); }
+                        else { if (ps.mode == 1) ps.bounce += 1; advance(1, 0.0f); }
                         want_bounce = ps.stage == ST_BOUNCE;
                     }
                 }
@@ -482,12 +485,12 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                 PT_STAMP_BEGIN();
                 if (!tr.alive && ps.stage == ST_SH) {
                     // traceWhitted's light-ray loop (reference :614-637): count unoccluded disk samples
-                    if (tr.pmin < 0) ps.terminate += 1.0f;
+                    if (tr.pmin < 0) ps.inv_n.x += 1.0f;
                     ps.bounce += 1;
                     if (ps.bounce < prm.num_light_rays) ps.stage = ST_WSHADOW;
                     else {
                         // reference :639-656
-                        const ptgpu_light& Lt = lights[ps.li];
+                        const ptgpu_light& Lt = lights[ps.li0];
                         F3 L = light_col(Lt, 3) - ps.O;
                         F3 D = normalize(L);
                         float d = length(L);
@@ -496,7 +499,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         F3 color = ps.diffuse * sel_max(0.0f, dot(ps.N, D));
                         color = color + ps.c * ptm_pow(sel_max(0.0f, dot(ps.N, H)), ps.gloss) * ps.normalization;
                         color = color * attenuation;
-                        color = color * (ps.terminate / (float)prm.num_light_rays);
+                        color = color * (ps.inv_n.x / (float)prm.num_light_rays);
                         ps.Ei = color;
                         finish();
                     }
