@@ -781,8 +781,12 @@ constexpr int PT_BLOCK = PT_BLOCK_THREADS;
 #endif
 
 template <bool COUNT, int NLDS, bool OVF>
-#ifdef PT_NUM_VGPR
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(PT_NUM_VGPR, PT_NUM_VGPR))) void k_integrate(
+#ifdef PT_WAVES_PER_EU
+// Diagnostic build: force the register allocator to a given occupancy.  5 waves/SIMD = 96 VGPRs + 236 B of scratch per lane: 27.3 ms per
+// 16 spp pass against 25.3 ms for the 4-wave / 128-VGPR build below (whose run time scales almost linearly with waves: 2 / 3 / 4 waves
+// per SIMD = 40.9 / 32.5 / 25.5 ms, measured by padding the workgroup's LDS) -- the kernel is latency-bound, but the state a lane
+// carries across a bounce does not fit 96 registers together with the hit block's temporaries.
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(PT_WAVES_PER_EU, PT_WAVES_PER_EU))) void k_integrate(
 #else
 __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void k_integrate(
 #endif
