@@ -13,6 +13,9 @@ run() { # name, rocprofv3 args...
     echo "pass $name rc=$rc"
     return $rc
 }
+# the bench command itself (the bench line's kernel durations must agree with this trace)
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/benchcmd" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > "$OUT/benchcmd.log" 2>&1
+echo "pass benchcmd rc=$?"
 run trace --kernel-trace --stats &&
 run fetch --pmc FETCH_SIZE &&
 run write --pmc WRITE_SIZE &&
