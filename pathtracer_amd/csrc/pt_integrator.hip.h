@@ -392,7 +392,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                 bool want_bounce = ps.stage == ST_BOUNCE || ps.stage == ST_REBOUNCE;
                 if (hit_lane) {
                     // hit set-up: reference :300-344 (first hit), :403-414 / :486-498 (bounce hits), :608-613 (Whitted)
-                    const float4 rec = TS.tris[(size_t)tr.pmin * 4 + 3];
+                    const float4 rec = tri_record(TS, tr.pmin)[3];
                     const int hit_tri = __float_as_int(rec.x), hit_mat = __float_as_int(rec.w);
                     const bool first = ps.mode == 0;
                     if (first || prm.whitted) {

@@ -35,8 +35,11 @@ struct DevTexture {
 };
 
 struct TravScene {
-    const float4* inner;  // [num_inner][4]
-    const float4* tris;   // [list_size][4]
+    // ONE array of 64-byte records addressed by the signed reference itself: interior node i at records[i], triangle record p (position
+    // in bvh.list) at records[~p] = records[-(p + 1)], i.e. the triangle records lie in reverse order below the interior ones.  A step's
+    // fetch address is records + ref * 64 whatever the reference is (no select between two bases), and "next triangle of this leaf"
+    // stays ref - 1.
+    const float4* records;
     float root_bmin[3], root_bmax[3];
     int32_t root_ref;     // >= 0: interior node index; < 0: leaf starting at triangle record ~root_ref
     int32_t list_size;    // 0 => empty scene, every ray misses
@@ -51,6 +54,8 @@ struct HitRec {
 };
 
 __device__ __forceinline__ float4 ldg4(const float4* p) { return *p; }
+// the 4 x float4 record of the triangle at position p of bvh.list
+__device__ __forceinline__ const float4* tri_record(const TravScene& S, int p) { return S.records + (ptrdiff_t)(~p) * 4; }
 
 // One child's slab test.  near*/far* are the box planes already selected by the ray's sign bits
 // (bounds[sign] / bounds[1-sign] in the reference).  Returns the t1-independent part of the result
@@ -217,7 +222,7 @@ struct Trav {
 
     // one step for a lane with alive == true
     __device__ __forceinline__ void step(const TravScene& S) {
-        const float4* rp = (cur >= 0) ? (S.inner + (size_t)cur * 4) : (S.tris + (size_t)(~cur) * 4);
+        const float4* rp = S.records + (ptrdiff_t)cur * 4;
         float4 a = ldg4(rp), b = ldg4(rp + 1), c = ldg4(rp + 2), m = ldg4(rp + 3);
         const bool sx = (signbits & 1u) != 0u, sy = (signbits & 2u) != 0u, sz = (signbits & 4u) != 0u;
         if (cur >= 0) {
@@ -292,7 +297,7 @@ struct Trav {
         HitRec h;
         h.id = -1; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f;
         if (pmin >= 0) {
-            h.id = __float_as_int(S.tris[(size_t)pmin * 4 + 3].x);
+            h.id = __float_as_int(tri_record(S, pmin)[3].x);
             h.t = tmin; h.u = umin; h.v = vmin;
         }
         return h;

@@ -68,8 +68,7 @@ struct ptgpu_scene {
     int32_t num_tris = 0, num_inner = 0, depth = 0;
     bool has_alpha = false;
     // device allocations
-    float4* d_inner = nullptr;
-    float4* d_tris = nullptr;
+    float4* d_records = nullptr;  // triangle records in reverse order, then the interior records (TravScene::records points between them)
     float *d_pos = nullptr, *d_nrm = nullptr, *d_uv = nullptr;
     int32_t* d_mat_id = nullptr;
     ptgpu_material* d_materials = nullptr;
@@ -351,8 +350,17 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
     s->depth = depth;
 
     int rc;
-    if ((rc = upload(c, &s->d_inner, inner.data(), inner.size(), &s->bytes[0]))) return rc;
-    if ((rc = upload(c, &s->d_tris, tris.data(), tris.size(), &s->bytes[1]))) return rc;
+    {
+        // one array: triangle record p at index (nl - 1 - p), interior record i at index nl + i  (records = base + nl records)
+        const size_t n_tri_rec = tris.size() / 4, n_in_rec = inner.size() / 4;
+        std::vector<float4> all((n_tri_rec + n_in_rec) * 4);
+        for (size_t p = 0; p < n_tri_rec; ++p) memcpy(&all[(n_tri_rec - 1 - p) * 4], &tris[p * 4], 64);
+        if (n_in_rec) memcpy(&all[n_tri_rec * 4], inner.data(), n_in_rec * 64);
+        if ((rc = upload(c, &s->d_records, all.data(), all.size(), nullptr))) return rc;
+        s->bytes[0] += inner.size() * sizeof(float4);
+        s->bytes[1] += tris.size() * sizeof(float4);
+        s->trav.records = s->d_records + n_tri_rec * 4;
+    }
     if ((rc = upload(c, &s->d_pos, d->pos, (size_t)nt * 9, &s->bytes[2]))) return rc;
     if ((rc = upload(c, &s->d_nrm, d->nrm, (size_t)nt * 9, &s->bytes[2]))) return rc;
     if ((rc = upload(c, &s->d_uv, d->uv, (size_t)nt * 6, &s->bytes[2]))) return rc;
@@ -366,8 +374,6 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
         tex[i].rgba = p; tex[i].width = d->textures[i].width; tex[i].height = d->textures[i].height;
     }
     if ((rc = upload(c, &s->d_textures, tex.data(), tex.size(), &s->bytes[3]))) return rc;
-    s->trav.inner = s->d_inner;
-    s->trav.tris = s->d_tris;
     s->trav.uv = s->d_uv;
     s->trav.textures = s->d_textures;
     return PTGPU_OK;
@@ -377,7 +383,7 @@ extern "C" int ptgpu_scene_destroy(ptgpu_scene* s) {
     if (!s) return PTGPU_OK;
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
-    void* ptrs[] = {s->d_inner, s->d_tris, s->d_pos, s->d_nrm, s->d_uv, s->d_mat_id, s->d_materials, s->d_textures};
+    void* ptrs[] = {s->d_records, s->d_pos, s->d_nrm, s->d_uv, s->d_mat_id, s->d_materials, s->d_textures};
     for (void* p : ptrs) if (p) hipFree(p);
     for (uint8_t* p : s->d_texels) if (p) hipFree(p);
     delete s;
