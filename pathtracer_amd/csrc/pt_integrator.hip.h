@@ -256,13 +256,13 @@ struct PathState {
 
 // One integrator launch.  rad[sid] = (Ei.rgb, aux) for every valid padded sample id of the launch's blocks.
 // spill: samples of Sobol-block mode whose pixel falls outside their own block (sobol() == 1.0f exactly, p = 2^-24).
-template <bool COUNT, int NLDS, bool OVF, int BLOCK>
+template <bool COUNT, int NLDS, bool OVF, int BLOCK, bool ALPHA>
 __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene& SS, const ptgpu_params& prm, const ptgpu_camera& cam,
                                           const ptgpu_light* __restrict__ lights, const PassDesc& pd, float4* __restrict__ rad,
                                           unsigned long long* counters, uint2* lds_lane, uint2* gl_lane, int service_threshold_packed) {
     const int service_threshold = service_threshold_packed & 0xff, control_min = (service_threshold_packed >> 8) & 0xff;
     const int lane = threadIdx.x & 63;
-    Trav<true, COUNT, NLDS, OVF> tr;
+    Trav<ALPHA, COUNT, NLDS, OVF> tr;
     tr.reset_counts();
     tr.attach(lds_lane, gl_lane);
     tr.alive = false;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                     ps.N = ps.N * -1.0f;
                     ps.stage = ST_REBOUNCE;
                 } else {
-                    typename Trav<true, COUNT, NLDS, OVF>::Prepared pr;
+                    typename Trav<ALPHA, COUNT, NLDS, OVF>::Prepared pr;
                     pr.inv = ps.inv_n;
                     pr.bits = ps.bits;
                     tr.launch(TS, ps.O + 0.0001f * ps.N, cam.far_ * ps.V, pr, false);
@@ -468,7 +468,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                     ps.V = normalize(basis_times(ps.N, f3(x, y, z)));
                     if (ps.stage != ST_REBOUNCE) ps.throughput = ps.throughput * ps.diffuse;
                     const F3 bo = ps.O + 0.0001f * ps.N, bd = cam.far_ * ps.V;
-                    const auto pr = Trav<true, COUNT, NLDS, OVF>::prepare(TS, bo, bd);
+                    const auto pr = Trav<ALPHA, COUNT, NLDS, OVF>::prepare(TS, bo, bd);
                     if (hit_lane) {  // the shadow ray goes first
                         ps.inv_n = pr.inv;
                         ps.bits |= pr.bits | PB_PENDING;

@@ -786,7 +786,7 @@ constexpr int PT_BLOCK = PT_BLOCK_THREADS;
                         // Measured on the configs[2] frame: 4 waves + 16 LDS stack entries 32.0 ms vs 3 waves + 24 entries 34.6 ms per 16 spp
 #endif
 
-template <bool COUNT, int NLDS, bool OVF>
+template <bool COUNT, int NLDS, bool OVF, bool ALPHA>
 #ifdef PT_WAVES_PER_EU
 // Diagnostic build: force the register allocator to a given occupancy.  5 waves/SIMD = 96 VGPRs + 236 B of scratch per lane: 27.3 ms per
 // 16 spp pass against 25.3 ms for the 4-wave / 128-VGPR build below (whose run time scales almost linearly with waves: 2 / 3 / 4 waves
@@ -802,7 +802,7 @@ ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
     __shared__ uint2 lds_stack[PT_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t wave_id = (size_t)blockIdx.x * (PT_BLOCK / 64) + wave;
-    ptd::integrate<COUNT, NLDS, OVF, PT_BLOCK>(TS, SS, prm, cam, lights, pd, rad, counters, &lds_stack[wave][0][lane],
+    ptd::integrate<COUNT, NLDS, OVF, PT_BLOCK, ALPHA>(TS, SS, prm, cam, lights, pd, rad, counters, &lds_stack[wave][0][lane],
                                                OVF ? stack_ovf + wave_id * (64 - NLDS) * 64 + lane : nullptr, service_threshold);
 }
 
@@ -934,7 +934,7 @@ static int check_params(const ptgpu_params* p) {
     return PTGPU_OK;
 }
 
-template <bool COUNT, int NLDS, bool OVF>
+template <bool COUNT, int NLDS, bool OVF, bool ALPHA>
 static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const ptd::ShadeScene& ss, const ptgpu_params* prm, const ptgpu_camera* cam,
                             const ptd::PassDesc& pd) {
     ptgpu_context* c = s->ctx;
@@ -942,7 +942,7 @@ static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const pt
     int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_integrate<COUNT, NLDS, OVF>, PT_BLOCK, 0) != hipSuccess || v < 1) v = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_integrate<COUNT, NLDS, OVF, ALPHA>, PT_BLOCK, 0) != hipSuccess || v < 1) v = 1;
         per_cu = v;
         per_cu_cache.store(v, std::memory_order_relaxed);
     }
@@ -954,7 +954,7 @@ static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const pt
         int rc = ensure_stack_overflow(c, (size_t)blocks * (PT_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
         if (rc != PTGPU_OK) return rc;
     }
-    hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(PT_BLOCK), (size_t)env_int("PTGPU_PT_EXTRA_LDS", 0), c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
+    hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF, ALPHA>), dim3((unsigned)blocks), dim3(PT_BLOCK), (size_t)env_int("PTGPU_PT_EXTRA_LDS", 0), c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
                        c->d_counters, env_int("PTGPU_PT_SERVICE", 32) | (env_int("PTGPU_PT_CTLMIN", 16) << 8), c->d_stack_ovf);
     return PTGPU_OK;
 }
@@ -1010,11 +1010,15 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
         pd.num_blocks = (count - j0 < batch_blocks) ? count - j0 : (int)batch_blocks;
         pd.blocks_x = blocks_x; pd.samples_per_block = (int32_t)spb; pd.num_lights = num_lights;
         pd.inv_prob = 1.0f / prm->termination_prob;
-        if (c->count) rc = launch_integrate<true, 16, true>(s, trav, ss, prm, cam, pd);
-        else if (nlds == 12) rc = launch_integrate<false, 12, true>(s, trav, ss, prm, cam, pd);
-        else if (stack_need > 24 || (stack_need > 16 && nlds == 16)) rc = launch_integrate<false, 16, true>(s, trav, ss, prm, cam, pd);
-        else if (nlds == 16) rc = launch_integrate<false, 16, false>(s, trav, ss, prm, cam, pd);
-        else rc = launch_integrate<false, 24, false>(s, trav, ss, prm, cam, pd);
+        // the alpha-cutout code is only compiled into the variants a scene with alpha maps takes (fewer registers for all others)
+#define PT_LAUNCH(COUNT_, NLDS_, OVF_) (trav.alpha_on ? launch_integrate<COUNT_, NLDS_, OVF_, true>(s, trav, ss, prm, cam, pd) \
+                                                      : launch_integrate<COUNT_, NLDS_, OVF_, false>(s, trav, ss, prm, cam, pd))
+        if (c->count) rc = launch_integrate<true, 16, true, true>(s, trav, ss, prm, cam, pd);
+        else if (nlds == 12) rc = PT_LAUNCH(false, 12, true);
+        else if (stack_need > 24 || (stack_need > 16 && nlds == 16)) rc = PT_LAUNCH(false, 16, true);
+        else if (nlds == 16) rc = PT_LAUNCH(false, 16, false);
+        else rc = PT_LAUNCH(false, 24, false);
+#undef PT_LAUNCH
         if (rc != PTGPU_OK) return rc;
         if (prm->sobol_block) {
             hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + 3, 1);
