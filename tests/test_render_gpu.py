@@ -186,3 +186,24 @@ def test_whitted_mode_exact(soup_gpu, textured_soup, oracle, sobol_block):
     c, ctr = oracle.render_pass(textured_soup, prm, cam, lights, nthreads=8)
     assert c[..., :3].max() > 0.01 and ctr["rays"] > w * h * 2
     _assert_image_exact(g, c, "whitted sobol_block=%s" % sobol_block)
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108])
+def test_randomised_settings_exact(soup_gpu, textured_soup, oracle, seed):
+    """Random draws over every switch the pass has (AA mode, fixed / roulette bounces, filtering, normal maps, alpha, depth of field,
+    Whitted, 1-3 lights, clipped image sizes): whatever the combination, the accumulation image is the oracle's, bit for bit."""
+    rng = np.random.RandomState(seed)
+    w, h = int(rng.randint(33, 90)), int(rng.randint(33, 70))
+    cam, lights = _soup_view(w, h)
+    lights = lights + [scene.make_light(position=(0.0, -0.8, 1.2), col0=(1, 0, 0), col1=(0, 1, 0), col2=(0, 0, 1), size=(0.2, 0.2), E=(30, 30, 50))]
+    lights = lights[: int(rng.randint(1, 4))]
+    whitted = bool(rng.rand() < 0.25)
+    prm = scene.make_params(width=w, height=h, bounces=int(rng.choice([-3, -2, -1, 0, 1, 2, 4])), num_aa_rays=int(rng.randint(1, 5)),
+                            sobol_block=bool(rng.rand() < 0.5), bilinear=bool(rng.rand() < 0.5), normal_mapped=bool(rng.rand() < 0.5),
+                            depth_of_field=bool(rng.rand() < 0.4), aperture=float(rng.uniform(0.001, 0.05)), focal_distance=float(rng.uniform(1.0, 3.0)),
+                            whitted=whitted, num_light_rays=int(rng.randint(1, 6)), use_alpha=bool(rng.rand() < 0.7),
+                            filter_width=float(rng.uniform(1.0, 2.0)), attenuation=float(rng.uniform(0.5, 1.5)), intensity=float(rng.uniform(0.5, 2.0)),
+                            termination_prob=float(rng.uniform(0.1, 0.6)), pass_seed=seed)
+    g = soup_gpu.render_pass(prm, cam, lights)
+    c, _ = oracle.render_pass(textured_soup, prm, cam, lights, nthreads=8)
+    _assert_image_exact(g, c, "seed %d" % seed)
