@@ -174,8 +174,10 @@ def main():
                         "shadow_nodes": cs["node_visits"] / n, "shadow_tris": cs["tri_tests"] / n},
             "roofline": {"kernel": "k_raycast_step<closest-hit>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "algorithmic bytes (64 B/node visit + 52 B/triangle test + 44 B/ray); head.obj's 1.1 MB of "
-                                 "nodes+triangles is L2-resident, so frac measures traversal rate, not HBM pressure"},
+                         "note": "algorithmic bytes (64 B/node visit + 52 B/triangle test + 44 B/ray); head.obj's 1.6 MB of "
+                                 "nodes+triangles is L2-resident, so frac measures traversal rate, not HBM pressure (`traffic` is what "
+                                 "reaches HBM: the rays in and the hit records out). Measured limiter: the vector L1 data path, "
+                                 "64 B per lane per step (TD_TD_BUSY 66 % of kernel cycles, L1 hit rate 98 %: profiles/l1a_pmc_summary.json)"},
         }
         if pt:
             out["path_trace"] = pt
