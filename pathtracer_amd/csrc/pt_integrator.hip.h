@@ -233,6 +233,10 @@ __device__ __forceinline__ int block_sobol_base(int idx, uint32_t pass_seed) {
 #define PT_STAMP_END(k, lanes) do {} while (0)
 #endif
 
+#ifndef PT_STEPS_PER_ITERATION
+#define PT_STEPS_PER_ITERATION 3
+#endif
+
 // per-lane path state between two service rounds
 //   ST_EXT      closest-hit ray in flight, or finished and waiting for the hit block
 //   ST_SH       shadow ray in flight; for path tracing everything that follows it is already decided (see "pending bounce")
@@ -615,7 +619,18 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
         }
         {
             PT_STAMP_BEGIN();
+            // several steps per scheduler iteration: the ballots and tests of the loop head are paid once for all of them
+            // (written out: as an unrolled loop the same code compiled to a 25 % slower kernel)
             if (tr.alive) tr.step(TS);
+#if PT_STEPS_PER_ITERATION >= 2
+            if (tr.alive) tr.step(TS);
+#endif
+#if PT_STEPS_PER_ITERATION >= 3
+            if (tr.alive) tr.step(TS);
+#endif
+#if PT_STEPS_PER_ITERATION >= 4
+            if (tr.alive) tr.step(TS);
+#endif
             PT_STAMP_END(6, __popcll(alive_mask));
         }
     }
