@@ -63,8 +63,10 @@ inline V2 ld2(const float* p) { return V2{p[0], p[1]}; }
 // Image::getVec4f on an 8-bit RGBA image: channel / 255 (FW's scale is unpinned).
 inline V4 texel(const pto_texture& t, int x, int y) {
     // reference indexes out of bounds when frac() rounds to 1.0; clamp
-    if (x < 0) x = 0; if (x > t.width - 1) x = t.width - 1;
-    if (y < 0) y = 0; if (y > t.height - 1) y = t.height - 1;
+    if (x < 0) x = 0;
+    if (x > t.width - 1) x = t.width - 1;
+    if (y < 0) y = 0;
+    if (y > t.height - 1) y = t.height - 1;
     const uint8_t* p = t.rgba + ((size_t)y * t.width + x) * 4;
     return V4{p[0] / 255.0f, p[1] / 255.0f, p[2] / 255.0f, p[3] / 255.0f};
 }
