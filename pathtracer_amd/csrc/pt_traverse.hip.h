@@ -220,6 +220,77 @@ struct Trav {
         }
     }
 
+    // interior-node half of a step, given the node's record
+    __device__ __forceinline__ void visit_node(float4 a, float4 b, float4 c, float4 m) {
+        const bool sx = (signbits & 1u) != 0u, sy = (signbits & 2u) != 0u, sz = (signbits & 4u) != 0u;
+        bool okL, okR; float teL, teR;
+        if (fast) {
+            slab_fast2(a, b, c, float2v{o.x, o.y}, float2v{inv.x, inv.y}, o.z, inv.z, okL, teL, okR, teR);
+        } else {
+            slab(sx ? a.z : a.x, sy ? a.w : a.y, sz ? c.y : c.x, sx ? a.x : a.z, sy ? a.y : a.w, sz ? c.x : c.y, o, inv, okL, teL);
+            slab(sx ? b.z : b.x, sy ? b.w : b.y, sz ? c.w : c.z, sx ? b.x : b.z, sy ? b.y : b.w, sz ? c.z : c.w, o, inv, okR, teR);
+        }
+        int refL = __float_as_int(m.x), refR = __float_as_int(m.y);
+        bool rightFirst = ((signbits >> __float_as_int(m.z)) & 1u) != 0u;
+        int refN = rightFirst ? refR : refL, refF = rightFirst ? refL : refR;
+        bool okN = rightFirst ? okR : okL, okF = rightFirst ? okL : okR;
+        float teN = rightFirst ? teR : teL, teF = rightFirst ? teL : teR;
+        bool passN = okN && (teN < tmin);
+        bool passF = okF && (teF < tmin);
+        if (COUNT) {
+            n_nodes += 1;
+            st.push(refF, passF ? teF : __uint_as_float(0x7f800000u));
+            passF = false;
+        }
+        if (passN) {
+            if (passF) st.push(refF, teF);
+            cur = refN;
+        } else if (passF) {
+            cur = refF;
+        } else {
+            pop_next();
+        }
+        if (DEFER && st.full) alive = false;
+    }
+    // triangle half of a step, given the triangle's record
+    __device__ __forceinline__ void test_triangle(const TravScene& S, float4 a, float4 b, float4 c, float4 m) {
+        if (COUNT) n_tris += 1;
+        float ox = (a.x * o.x + a.y * o.y + a.z * o.z) + a.w;
+        float oy = (b.x * o.x + b.y * o.y + b.z * o.z) + b.w;
+        float oz = (c.x * o.x + c.y * o.y + c.z * o.z) + c.w;
+        float dx = a.x * d.x + a.y * d.y + a.z * d.z;
+        float dy = b.x * d.x + b.y * d.y + b.z * d.z;
+        float dz = c.x * d.x + c.y * d.y + c.z * d.z;
+        float t = -oz / dz;
+        float u = ox + dx * t;
+        float v = oy + dy * t;
+        bool done = false;
+        if (u > 0.0f && v > 0.0f && u + v < 1.0f) {
+            bool keep = true;
+            if (ALPHA) {
+                int atex = __float_as_int(m.z);
+                if (S.alpha_on && atex >= 0) {
+                    const float* tc = S.uv + (size_t)__float_as_int(m.x) * 6;
+                    F2 uv = (1 - u - v) * ld2(tc) + u * ld2(tc + 2) + v * ld2(tc + 4);
+                    DevTexture tx = S.textures[atex];
+                    int x = (int)((uv.x - floorf(uv.x)) * tx.width);
+                    int y = (int)((uv.y - floorf(uv.y)) * tx.height);
+                    x = x < 0 ? 0 : (x > tx.width - 1 ? tx.width - 1 : x);
+                    y = y < 0 ? 0 : (y > tx.height - 1 ? tx.height - 1 : y);
+                    float alpha = (float)tx.rgba[((size_t)y * tx.width + x) * 4 + 1] / 255.0f;
+                    keep = !(alpha < 0.5f);
+                }
+            }
+            if (keep && t > 0.0f && t < tmin) {
+                pmin = ~cur; tmin = t; umin = u; vmin = v;
+                done = anyhit;
+            }
+        }
+        if (done) alive = false;
+        else if (__float_as_int(m.y) != 0) cur -= 1;  // next record of this leaf: ~(pos + 1) == cur - 1
+        else pop_next();
+    }
+
     // one step for a lane with alive == true
     __device__ __forceinline__ void step(const TravScene& S) {
         const float4* rp = S.records + (ptrdiff_t)cur * 4;
@@ -291,6 +362,18 @@ struct Trav {
             else if (__float_as_int(m.y) != 0) cur -= 1;  // next record of this leaf: ~(pos + 1) == cur - 1
             else pop_next();
         }
+    }
+    // (step() above stays one body of its own: routed through visit_node / test_triangle the one-ray-per-lane kernels compiled 4 % slower)
+    // the same for callers that run the two kinds of step in separate, wave-uniform phases (pt_integrator.hip.h): a wave whose lanes
+    // are all at interior nodes, or all at triangles, executes one half of step()'s code instead of both
+    __device__ __forceinline__ bool at_node() const { return cur >= 0; }
+    __device__ __forceinline__ void step_node(const TravScene& S) {
+        const float4* rp = S.records + (ptrdiff_t)cur * 4;
+        visit_node(ldg4(rp), ldg4(rp + 1), ldg4(rp + 2), ldg4(rp + 3));
+    }
+    __device__ __forceinline__ void step_triangle(const TravScene& S) {
+        const float4* rp = S.records + (ptrdiff_t)cur * 4;
+        test_triangle(S, ldg4(rp), ldg4(rp + 1), ldg4(rp + 2), ldg4(rp + 3));
     }
 
     __device__ __forceinline__ HitRec result(const TravScene& S) const {
