@@ -34,6 +34,7 @@ from pathtracer_amd import capi, hostapi, multigpu, scene  # noqa: E402
 
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+GATHER_PEAK_GBS, GATHER_INCOHERENT_GBS = 37950.0, 14230.0  # measured: tools/l1_gather_peak.hip, profiles/r01_n_l1_gather_peak.jsonl
 PT_SPP = 256
 
 
@@ -177,7 +178,13 @@ def main():
                          "note": "algorithmic bytes (64 B/node visit + 52 B/triangle test + 44 B/ray); head.obj's 1.6 MB of "
                                  "nodes+triangles is L2-resident, so frac measures traversal rate, not HBM pressure (`traffic` is what "
                                  "reaches HBM: the rays in and the hit records out). Measured limiter: the vector L1 data path, "
-                                 "64 B per lane per step (TD_TD_BUSY 66 % of kernel cycles, L1 hit rate 98 %: profiles/l1a_pmc_summary.json)"},
+                                 "64 B per lane per step (TD_TD_BUSY 66 % of kernel cycles, L1 hit rate 98 %: profiles/l1a_pmc_summary.json)",
+                         "cache_gather": {"achieved": achieved, "peak": GATHER_PEAK_GBS, "peak_incoherent": GATHER_INCOHERENT_GBS,
+                                          "unit": "GB/s", "frac": achieved / GATHER_PEAK_GBS,
+                                          "note": "the bound that applies: 64-byte records gathered per lane from cache, measured on this "
+                                                  "GPU by tools/l1_gather_peak.hip (profiles/r01_n_l1_gather_peak.jsonl): `peak` with >= 4 "
+                                                  "neighbouring lanes on the same record (64 B/clk/CU), `peak_incoherent` with every "
+                                                  "lane on its own record; same rate from a 16 KiB and a 4 MiB table"}},
         }
         if pt:
             out["path_trace"] = pt
