@@ -295,7 +295,6 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
     uint32_t next = 0, end = 0, round = 0xffffffffu;
     bool exhausted = false;
     const int bounces = prm.bounces < 0 ? -prm.bounces : prm.bounces;
-    const float div_x = 1.0f / (float)prm.width, div_y = 1.0f / (float)prm.height;
     const float PI = 3.14159265358979323846f;
 
     // finish a sample: its radiance leaves through rad[], the lane becomes idle
@@ -540,46 +539,53 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                     const int avail = (int)(end - next);
                     const int rank = __popcll(need & ((1ull << lane) - 1ull));
                     if (ps.stage == ST_IDLE && rank < avail) {
+                        // The uniform divisors and sizes of this block pass through an empty asm: everything derived from them
+                        // (reciprocals, division magic, int->float) is then computed here, per batch of new samples, instead of
+                        // being hoisted out of the kernel's loop into VGPRs that stay occupied (and spilled) for its whole life.
+                        int n_width = prm.width, n_height = prm.height, n_spb = pd.samples_per_block, n_blocks_x = pd.blocks_x, n_aa = prm.num_aa_rays;
+                        float n_filter = prm.filter_width;
+                        asm volatile("" : "+s"(n_width), "+s"(n_height), "+s"(n_spb), "+s"(n_blocks_x), "+s"(n_aa), "+s"(n_filter));
+                        const float div_x = 1.0f / (float)n_width, div_y = 1.0f / (float)n_height;
                         const int sid = (int)(next + (uint32_t)rank);
-                        const int jj = (int)((uint32_t)sid / (uint32_t)pd.samples_per_block);
-                        const int s = sid - jj * pd.samples_per_block;
+                        const int jj = (int)((uint32_t)sid / (uint32_t)n_spb);
+                        const int s = sid - jj * n_spb;
                         const int idx = pd.block_begin + (pd.j0 + jj) * pd.block_stride;
-                        const int bx = (idx % pd.blocks_x) * 32, by = (idx / pd.blocks_x) * 32;
-                        const int bw = (bx + 32 < prm.width) ? 32 : prm.width - bx;
-                        const int bh = (by + 32 < prm.height) ? 32 : prm.height - by;
+                        const int bx = (idx % n_blocks_x) * 32, by = (idx / n_blocks_x) * 32;
+                        const int bw = (bx + 32 < n_width) ? 32 : n_width - bx;
+                        const int bh = (by + 32 < n_height) ? 32 : n_height - by;
                         const int base = block_sobol_base(idx, prm.pass_seed);
                         bool valid;
                         float px, py;
                         int sbase;
                         if (prm.sobol_block) {  // reference :706-727
                             const int i = s;
-                            valid = i < bw * bh * prm.num_aa_rays;
+                            valid = i < bw * bh * n_aa;
                             float sa, sb;
                             sobol32x2(SS.sobol_pairs, (uint32_t)(base + i), 0u, sa, sb);
                             px = (float)bx + (float)bw * sa;
                             py = (float)by + (float)bh * sb;
                             sbase = base + i;
                             ps.R.seed((uint32_t)idx, prm.pass_seed, (uint32_t)i, 0u);
-                            int pixel_x = (int)floorf(px); if (pixel_x > prm.width - 1) pixel_x = prm.width - 1;
-                            int pixel_y = (int)floorf(py); if (pixel_y > prm.height - 1) pixel_y = prm.height - 1;
-                            ps.aux = __int_as_float(pixel_y * prm.width + pixel_x);  // global pixel index; accumulate checks the block
+                            int pixel_x = (int)floorf(px); if (pixel_x > n_width - 1) pixel_x = n_width - 1;
+                            int pixel_y = (int)floorf(py); if (pixel_y > n_height - 1) pixel_y = n_height - 1;
+                            ps.aux = __int_as_float(pixel_y * n_width + pixel_x);  // global pixel index; accumulate checks the block
                         } else {  // reference :743-779
-                            const int i = s / prm.num_aa_rays, k = s - i * prm.num_aa_rays;
+                            const int i = s / n_aa, k = s - i * n_aa;
                             valid = i < bw * bh;
                             const int pixel_x = bx + (i % bw), pixel_y = by + (i / bw);
                             float sa, sb;
                             sobol32x2(SS.sobol_pairs, (uint32_t)(base + i + k), 0u, sa, sb);
-                            float a = prm.filter_width * (sa - 0.5f) + 0.5f;
-                            float b = prm.filter_width * (sb - 0.5f) + 0.5f;
+                            float a = n_filter * (sa - 0.5f) + 0.5f;
+                            float b = n_filter * (sb - 0.5f) + 0.5f;
                             px = (float)pixel_x + a;
                             py = (float)pixel_y + b;
                             if (px < 0.0f) px *= -1.0f;
                             if (py < 0.0f) py *= -1.0f;
-                            if (px > (float)prm.width) px -= a;
-                            if (py > (float)prm.height) py -= b;
+                            if (px > (float)n_width) px -= a;
+                            if (py > (float)n_height) py -= b;
                             sbase = base + i;
                             ps.R.seed((uint32_t)idx, prm.pass_seed, (uint32_t)i, (uint32_t)k);
-                            const float fs = 2.0f / prm.filter_width;
+                            const float fs = 2.0f / n_filter;
                             ps.aux = gauss(fs * (a - 0.5f), fs * (b - 0.5f));
                         }
                         if (valid) {
