@@ -43,6 +43,8 @@ def textured_soup(oracle):
     mat_id = np.concatenate([rng.randint(0, 2, n), [1, 1]]).astype(np.int32)
     tex = [scene.value_noise_texture(1, 64), scene.value_noise_texture(2, 64, normal_map=True),
            scene.value_noise_texture(3, 32), scene.value_noise_texture(4, 48)]
+    # sizes that are not whole device tiles (8 x 4 texels), not square
+    tex[0], tex[2], tex[3] = tex[0][:61, :59].copy(), tex[2][:30, :27].copy(), tex[3][:45, :43].copy()
     tex[3][..., 1] = (tex[3][..., 0] > 150) * 255  # alpha map: green channel decides
     mats = [scene.make_material(diffuse=(0.7, 0.6, 0.5, 1), specular=(0.15, 0.15, 0.15), glossiness=50.0, tex_diffuse=0, tex_normal=1,
                                 tex_specular=2, tex_alpha=3),
