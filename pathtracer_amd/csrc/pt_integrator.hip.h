@@ -51,15 +51,19 @@ __device__ __forceinline__ float div255(float x) {
     return __builtin_fmaf(r, y, q);
 }
 
-__device__ __forceinline__ F4 texel(const DevTexture& t, int x, int y) {
+// a texel in two halves, so that a caller can issue several fetches before it consumes the first
+__device__ __forceinline__ uint32_t texel_fetch(const DevTexture& t, int x, int y) {
     x = x < 0 ? 0 : (x > t.width - 1 ? t.width - 1 : x);
     y = y < 0 ? 0 : (y > t.height - 1 ? t.height - 1 : y);
-    const uint32_t p = *reinterpret_cast<const uint32_t*>(t.rgba + ((size_t)y * t.width + x) * 4);
+    return *reinterpret_cast<const uint32_t*>(t.rgba + ((size_t)y * t.width + x) * 4);
+}
+__device__ __forceinline__ F4 texel_unpack(uint32_t p) {
     F4 r;
     r.x = div255((float)(p & 0xffu)); r.y = div255((float)((p >> 8) & 0xffu));
     r.z = div255((float)((p >> 16) & 0xffu)); r.w = div255((float)(p >> 24));
     return r;
 }
+__device__ __forceinline__ F4 texel(const DevTexture& t, int x, int y) { return texel_unpack(texel_fetch(t, x, y)); }
 __device__ __forceinline__ void texel_coords(F2 uv, const DevTexture& t, int& x, int& y) {
     x = (int)((uv.x - floorf(uv.x)) * (float)t.width);
     y = (int)((uv.y - floorf(uv.y)) * (float)t.height);
@@ -153,25 +157,50 @@ __device__ __forceinline__ void get_texture_parameters(const ShadeScene& S, cons
     F2 uv0 = ld2(tc), uv1 = ld2(tc + 2), uv2 = ld2(tc + 4);
     F2 uv = (1 - hu - hv) * uv0 + hu * uv1 + hv * uv2;
 
-    diffuse = f3(mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]);
-    if (mat.tex_diffuse >= 0) {
+    // Every texel this hit needs is fetched before the first is used: the maps live beyond L2 (Infinity Cache or HBM), and three
+    // dependent miss latencies in a row (diffuse, normal, specular) become one.
+    const bool has_d = mat.tex_diffuse >= 0, has_n = mat.tex_normal >= 0 && prm.normal_mapped, has_s = mat.tex_specular >= 0;
+    uint32_t rd1 = 0, rd2 = 0, rd3 = 0, rd4 = 0, rn = 0, rs = 0;
+    float w1 = 0.0f, w2 = 0.0f, w3 = 0.0f, w4 = 0.0f;
+    if (has_d) {
         DevTexture tex = S.textures[mat.tex_diffuse];
         if (prm.bilinear) {
             float fx = uv.x - floorf(uv.x);
             float fy = uv.y - floorf(uv.y);
             float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
-            float w1 = fx1 * fy1, w2 = fx * fy1, w3 = fx1 * fy, w4 = fx * fy;
+            w1 = fx1 * fy1; w2 = fx * fy1; w3 = fx1 * fy; w4 = fx * fy;
             int x1 = (int)sel_min(sel_max(fx * (float)tex.width - 0.5f, 0.0f), (float)tex.width - 2.0f);
             int y1 = (int)sel_min(sel_max(fy * (float)tex.height - 0.5f, 0.0f), (float)tex.height - 2.0f);
             int x2 = x1 + 1, y2 = y1 + 1;
-            F4 d1 = texel(tex, x1, y1), d2 = texel(tex, x2, y1), d3 = texel(tex, x1, y2), d4 = texel(tex, x2, y2);
+            rd1 = texel_fetch(tex, x1, y1); rd2 = texel_fetch(tex, x2, y1); rd3 = texel_fetch(tex, x1, y2); rd4 = texel_fetch(tex, x2, y2);
+        } else {
+            int x, y;
+            texel_coords(uv, tex, x, y);
+            rd1 = texel_fetch(tex, x, y);
+        }
+    }
+    if (has_n) {
+        DevTexture tex = S.textures[mat.tex_normal];
+        int x, y;
+        texel_coords(uv, tex, x, y);
+        rn = texel_fetch(tex, x, y);
+    }
+    if (has_s) {
+        DevTexture tex = S.textures[mat.tex_specular];
+        int x, y;
+        texel_coords(uv, tex, x, y);
+        rs = texel_fetch(tex, x, y);
+    }
+
+    diffuse = f3(mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]);
+    if (has_d) {
+        if (prm.bilinear) {
+            F4 d1 = texel_unpack(rd1), d2 = texel_unpack(rd2), d3 = texel_unpack(rd3), d4 = texel_unpack(rd4);
             diffuse = f3(d1.x * w1 + d2.x * w2 + d3.x * w3 + d4.x * w4,
                          d1.y * w1 + d2.y * w2 + d3.y * w3 + d4.y * w4,
                          d1.z * w1 + d2.z * w2 + d3.z * w3 + d4.z * w4);
         } else {
-            int x, y;
-            texel_coords(uv, tex, x, y);
-            F4 d = texel(tex, x, y);
+            F4 d = texel_unpack(rd1);
             diffuse = f3(d.x, d.y, d.z);
         }
         diffuse = f3(ptm_pow(diffuse.x, 2.2f), ptm_pow(diffuse.y, 2.2f), ptm_pow(diffuse.z, 2.2f));
@@ -179,11 +208,8 @@ __device__ __forceinline__ void get_texture_parameters(const ShadeScene& S, cons
     const float* nn = S.nrm + (size_t)tri * 9;
     n = normalize((1 - hu - hv) * ld3(nn) + hu * ld3(nn + 3) + hv * ld3(nn + 6));
 
-    if (mat.tex_normal >= 0 && prm.normal_mapped) {
-        DevTexture tex = S.textures[mat.tex_normal];
-        int x, y;
-        texel_coords(uv, tex, x, y);
-        F4 tv = texel(tex, x, y);
+    if (has_n) {
+        F4 tv = texel_unpack(rn);
         F3 texture_normal = f3(2.0f * tv.x - 1.0f, 2.0f * tv.y - 1.0f, 2.0f * tv.z - 1.0f);
         const float* pp = S.pos + (size_t)tri * 9;
         F3 v0 = ld3(pp), v1 = ld3(pp + 3), v2 = ld3(pp + 6);
@@ -197,11 +223,8 @@ __device__ __forceinline__ void get_texture_parameters(const ShadeScene& S, cons
                          tangent.z * tn.x + bitangent.z * tn.y + n.z * tn.z));
     }
     specular = f3(mat.specular[0], mat.specular[1], mat.specular[2]);
-    if (mat.tex_specular >= 0) {
-        DevTexture tex = S.textures[mat.tex_specular];
-        int x, y;
-        texel_coords(uv, tex, x, y);
-        F4 d = texel(tex, x, y);
+    if (has_s) {
+        F4 d = texel_unpack(rs);
         specular = f3(d.x, d.y, d.z);
     }
 }
