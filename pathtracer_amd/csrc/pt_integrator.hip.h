@@ -156,12 +156,15 @@ __device__ __forceinline__ void get_texture_parameters(const ShadeScene& S, cons
     const float* tc = S.uv + (size_t)tri * 6;
     F2 uv0 = ld2(tc), uv1 = ld2(tc + 2), uv2 = ld2(tc + 4);
     F2 uv = (1 - hu - hv) * uv0 + hu * uv1 + hv * uv2;
+    const float* nn = S.nrm + (size_t)tri * 9;
+    const F3 nrm0 = ld3(nn), nrm1 = ld3(nn + 3), nrm2 = ld3(nn + 6);  // issued here, used after the texels
 
     // Every texel this hit needs is fetched before the first is used: the maps live beyond L2 (Infinity Cache or HBM), and three
     // dependent miss latencies in a row (diffuse, normal, specular) become one.
     const bool has_d = mat.tex_diffuse >= 0, has_n = mat.tex_normal >= 0 && prm.normal_mapped, has_s = mat.tex_specular >= 0;
     uint32_t rd1 = 0, rd2 = 0, rd3 = 0, rd4 = 0, rn = 0, rs = 0;
     float w1 = 0.0f, w2 = 0.0f, w3 = 0.0f, w4 = 0.0f;
+    F3 v0 = f3(0.0f, 0.0f, 0.0f), v1 = v0, v2 = v0;  // the triangle's corners, for the tangent frame of a normal map
     if (has_d) {
         DevTexture tex = S.textures[mat.tex_diffuse];
         if (prm.bilinear) {
@@ -184,6 +187,8 @@ __device__ __forceinline__ void get_texture_parameters(const ShadeScene& S, cons
         int x, y;
         texel_coords(uv, tex, x, y);
         rn = texel_fetch(tex, x, y);
+        const float* pp = S.pos + (size_t)tri * 9;
+        v0 = ld3(pp); v1 = ld3(pp + 3); v2 = ld3(pp + 6);
     }
     if (has_s) {
         DevTexture tex = S.textures[mat.tex_specular];
@@ -205,14 +210,11 @@ __device__ __forceinline__ void get_texture_parameters(const ShadeScene& S, cons
         }
         diffuse = f3(ptm_pow(diffuse.x, 2.2f), ptm_pow(diffuse.y, 2.2f), ptm_pow(diffuse.z, 2.2f));
     }
-    const float* nn = S.nrm + (size_t)tri * 9;
-    n = normalize((1 - hu - hv) * ld3(nn) + hu * ld3(nn + 3) + hv * ld3(nn + 6));
+    n = normalize((1 - hu - hv) * nrm0 + hu * nrm1 + hv * nrm2);
 
     if (has_n) {
         F4 tv = texel_unpack(rn);
         F3 texture_normal = f3(2.0f * tv.x - 1.0f, 2.0f * tv.y - 1.0f, 2.0f * tv.z - 1.0f);
-        const float* pp = S.pos + (size_t)tri * 9;
-        F3 v0 = ld3(pp), v1 = ld3(pp + 3), v2 = ld3(pp + 6);
         F3 deltaPos1 = v1 - v0, deltaPos2 = v2 - v0;
         F2 deltaUV1 = uv1 - uv0, deltaUV2 = uv2 - uv0;
         float r = 1.0f / (deltaUV1.x * deltaUV2.y - deltaUV1.y * deltaUV2.x);
