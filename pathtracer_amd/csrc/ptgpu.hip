@@ -211,7 +211,8 @@ extern "C" int ptgpu_get_counters(ptgpu_context* c, ptgpu_counters* out) {
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2];
     return PTGPU_OK;
 }
-// Diagnostic (not declared in include/ptgpu.h): raw copy of all counter words, for PT_STAMPS builds.
+#ifdef PT_STAMPS
+// Diagnostic builds only (not declared in include/ptgpu.h, absent from the shipped library): raw copy of all counter words.
 extern "C" int ptgpu_debug_counters(ptgpu_context* c, unsigned long long* out32) {
     if (!c || !out32) return fail(PTGPU_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -219,6 +220,7 @@ extern "C" int ptgpu_debug_counters(ptgpu_context* c, unsigned long long* out32)
     HIP_TRY(hipMemcpy(out32, c->d_counters, CTR_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PTGPU_OK;
 }
+#endif
 extern "C" int ptgpu_reset_counters(ptgpu_context* c) {
     if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));

@@ -20,6 +20,12 @@ def test_cabi_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert getattr(lib, name) is not None
+    # and nothing beyond the header is exported under the library's prefix
+    import subprocess
+    path = os.environ.get("PTGPU_LIB") or os.path.join(ROOT, "pathtracer_amd", "libptgpu.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in syms.splitlines() if " T ptgpu_" in ln}
+    assert exported == declared, exported ^ declared
 
 
 def test_cabi_struct_layouts_match_header():
