@@ -5,6 +5,8 @@ The oracle is run with its portable transcendentals (libm=False): the HIP kernel
 with the same un-fused fp32 arithmetic, and pixels are accumulated in the reference's sample order, so the accumulation
 image must be BIT-EXACT, not merely close.  The oracle's libm variant (what the reference calls) is compared by RMSE:
 tolerance 2e-3 per-pixel RMSE and 1e-3 relative mean luminance on the resolved image (north_star's image criterion)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -190,7 +192,16 @@ def test_whitted_mode_exact(soup_gpu, textured_soup, oracle, sobol_block):
     _assert_image_exact(g, c, "whitted sobol_block=%s" % sobol_block)
 
 
-@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108])
+# PT_TEST_SEEDS="200-260" widens the sweep for a soak run (python -m pytest tests/test_render_gpu.py -k randomised)
+def _seeds():
+    spec = os.environ.get("PT_TEST_SEEDS", "")
+    if not spec:
+        return [101, 102, 103, 104, 105, 106, 107, 108]
+    lo, _, hi = spec.partition("-")
+    return list(range(int(lo), int(hi or lo) + 1))
+
+
+@pytest.mark.parametrize("seed", _seeds())
 def test_randomised_settings_exact(soup_gpu, textured_soup, oracle, seed):
     """Random draws over every switch the pass has (AA mode, fixed / roulette bounces, filtering, normal maps, alpha, depth of field,
     Whitted, 1-3 lights, clipped image sizes): whatever the combination, the accumulation image is the oracle's, bit for bit."""
