@@ -12,6 +12,7 @@
 
 #include "../../include/ptgpu.h"
 #include "pt_traverse.hip.h"
+#include "pt_raycast_step.h"
 #include "pt_integrator.hip.h"
 #include "pt_lbvh.hip.h"
 
@@ -420,46 +421,7 @@ extern "C" int ptgpu_scene_stats(const ptgpu_scene* s, uint64_t out_bytes[4], in
 // kernels
 // ------------------------------------------------------------------------------------------------
 constexpr int RC_BLOCK = 256;      // persistent raycast kernel: 4 long-lived waves per workgroup
-// One-ray-per-lane kernel: ONE wave per workgroup.  A workgroup keeps its LDS and wave slots until its slowest wave ends, so
-// with 4 waves the three faster ones idle; measured on the configs[1] frame 64 vs 256 threads: closest 0.153 vs 0.160 ms,
-// any-hit 0.188 vs 0.236 ms, incoherent 0.296 vs 0.375 ms.
-constexpr int RC_STEP_BLOCK = 64;
-
-// One ray per lane for the lane's whole life (no refill), step-wise traverser.  Never built with global-memory stack overflow:
-// a grid of n/64 workgroups has no bounded set of waves to give overflow regions to.
-// DEFER: the tree may need more than NLDS entries; a ray that does is given up here (nothing written out of bounds) and its index
-// appended to defer_list (count in counters[5]) for k_raycast_persist's overflow variant to trace.
-template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool DEFER>
-__global__ __launch_bounds__(RC_STEP_BLOCK) void k_raycast_step(ptd::TravScene S, const float* __restrict__ orig, const float* __restrict__ dir,
-                                                           long long n, int32_t* __restrict__ out_id, float* __restrict__ out_t,
-                                                           float* __restrict__ out_u, float* __restrict__ out_v, unsigned long long* counters,
-                                                           int32_t* __restrict__ defer_list) {
-    __shared__ uint2 lds_stack[RC_STEP_BLOCK / 64][NLDS][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long i = (long long)blockIdx.x * RC_STEP_BLOCK + threadIdx.x;
-    if (i == 0) atomicAdd(&counters[0], (unsigned long long)n);  // 1 ray = 1 raycast() call (reference src/RayTracer.cpp:192)
-    ptd::Trav<ALPHA, COUNT, NLDS, false, DEFER> tr;
-    tr.reset_counts();
-    tr.attach(&lds_stack[wave][0][lane], nullptr);
-    tr.alive = false;
-    if (i < n) {
-        tr.begin(S, ptd::ld3(orig + i * 3), ptd::ld3(dir + i * 3), ANYHIT);
-        while (tr.alive) tr.step(S);
-        if (tr.deferred()) {
-            defer_list[atomicAdd(&counters[5], 1ull)] = (int32_t)i;  // at most n entries: the list holds n
-        } else {
-            ptd::HitRec h = tr.result(S);
-            if (out_id) out_id[i] = h.id;
-            if (out_t) out_t[i] = h.t;
-            if (out_u) out_u[i] = h.u;
-            if (out_v) out_v[i] = h.v;
-        }
-    }
-    if (COUNT) {
-        atomicAdd(&counters[1], (unsigned long long)tr.n_nodes);
-        atomicAdd(&counters[2], (unsigned long long)tr.n_tris);
-    }
-}
+constexpr int RC_STEP_BLOCK = ptd::RC_STEP_BLOCK;  // one-ray-per-lane kernels: pt_raycast_step.hip, a translation unit of its own
 
 // Long-lived waves with refill: wave w of W owns one chunk of RC_CHUNK consecutive rays out of every W consecutive chunks and hands
 // fresh rays to its idle lanes in batches (ballot + prefix count), so lanes do not idle while the wave's slowest ray
@@ -597,7 +559,6 @@ static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long l
     // 16: 2.14/2.03, 24: 2.73/2.56.
     const bool small_scene = s->bytes[0] + s->bytes[1] <= (4u << 20) && need <= 24;
     const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : (need <= 24 ? 12 : 16));
-    dim3 grid((unsigned)((n + RC_STEP_BLOCK - 1) / RC_STEP_BLOCK)), block(RC_STEP_BLOCK);
     if constexpr (COUNT || ALPHA) {  // rare variants: one configuration that is valid for every depth
         return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
     } else {
@@ -619,16 +580,7 @@ static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long l
             }
             hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + 5, 1);
         }
-#define PT_RC_STEP(N)                                                                                                                                  \
-    do {                                                                                                                                              \
-        if (defer) hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, N, true>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer); \
-        else hipLaunchKernelGGL((k_raycast_step<ANYHIT, ALPHA, COUNT, N, false>), grid, block, 0, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);      \
-    } while (0)
-        if (nlds == 8) PT_RC_STEP(8);
-        else if (nlds == 12) PT_RC_STEP(12);
-        else if (nlds == 16) PT_RC_STEP(16);
-        else PT_RC_STEP(24);
-#undef PT_RC_STEP
+        ptd::launch_raycast_step(ANYHIT, nlds, defer, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
         if (defer) {
             // the number of deferred rays is only known on the device: a small fixed grid, the kernel reads the count itself
             const long long expected = n / 64 < 65536 ? 65536 : n / 64;
