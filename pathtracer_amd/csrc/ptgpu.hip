@@ -845,7 +845,21 @@ __global__ __launch_bounds__(256) void k_accum_gauss(ptgpu_params prm, ptd::Pass
         const int pixel_x = bx + (i % bw), pixel_y = by + (i / bw);
         const float4* src = rad + (size_t)jj * pd.samples_per_block + (size_t)i * prm.num_aa_rays;
         float cx = 0.0f, cy = 0.0f, cz = 0.0f, cw = 0.0f;
-        for (int k = 0; k < prm.num_aa_rays; ++k) {
+        // a pixel's samples are contiguous: eight at a time (one 128-byte line when aligned), all loads issued before the first sum, so a
+        // line is used up while it is there (one load per trip re-fetched lines that 16 waves per CU had pushed out of the 32 KB L1);
+        // the sums stay in sample order
+        int k = 0;
+        for (; k + 8 <= prm.num_aa_rays; k += 8) {
+            float4 r[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = src[k + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float g = r[q].w;
+                cx += g * r[q].x; cy += g * r[q].y; cz += g * r[q].z; cw += g * 1.0f;
+            }
+        }
+        for (; k < prm.num_aa_rays; ++k) {
             const float4 r = src[k];
             const float g = r.w;
             cx += g * r.x; cy += g * r.y; cz += g * r.z; cw += g * 1.0f;

@@ -192,6 +192,19 @@ def test_whitted_mode_exact(soup_gpu, textured_soup, oracle, sobol_block):
     _assert_image_exact(g, c, "whitted sobol_block=%s" % sobol_block)
 
 
+@pytest.mark.parametrize("spp", [8, 19])
+def test_gaussian_many_samples_per_pixel_exact(soup_gpu, textured_soup, oracle, spp):
+    """Gaussian AA with 8 and more samples per pixel: k_accum_gauss sums them eight loads at a time plus a remainder, still in sample
+    order, so the normalised, saturated pixel is the sequential loop's (reference :743-790)."""
+    w, h = 45, 37
+    cam, lights = _soup_view(w, h)
+    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=spp, sobol_block=False, bilinear=True, normal_mapped=True,
+                            filter_width=1.5, termination_prob=0.3, pass_seed=spp)
+    g = soup_gpu.render_pass(prm, cam, lights)
+    c, _ = oracle.render_pass(textured_soup, prm, cam, lights, nthreads=8)
+    _assert_image_exact(g, c, "gaussian spp=%d" % spp)
+
+
 # PT_TEST_SEEDS="200-260" widens the sweep for a soak run (python -m pytest tests/test_render_gpu.py -k randomised)
 def _seeds():
     spec = os.environ.get("PT_TEST_SEEDS", "")
