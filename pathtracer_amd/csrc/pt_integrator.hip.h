@@ -281,7 +281,7 @@ __device__ __forceinline__ int block_sobol_base(int idx, uint32_t pass_seed) {
 #define PT_PHASE_BIAS_N 1
 #endif
 #ifndef PT_PHASE_BIAS_T
-#define PT_PHASE_BIAS_T 2  // a node phase only when node lanes outnumber triangle lanes 2:1 (measured: 1:1 21.2 ms, 2:1 20.6, 3:1 21.0)
+#define PT_PHASE_BIAS_T 1  // a node phase when node lanes are at least as many as triangle lanes (with wave priorities: 1:1 19.2 ms, 2:1 19.45, 3:1 19.8; without them 2:1 was best)
 #endif
 #ifndef PT_STEPS_PER_ITERATION
 #define PT_STEPS_PER_ITERATION 3
