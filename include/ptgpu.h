@@ -166,6 +166,18 @@ int ptgpu_raycast_batch(ptgpu_scene* scene, int use_alpha, const float* orig, co
 int ptgpu_raycast_batch_dev(ptgpu_scene* scene, int use_alpha, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
                             int32_t* d_id, float* d_t, float* d_u, float* d_v);
 
+/* The one entry point that ALLOCATES NOTHING.  It has no counterpart in the reference (whose raycast() never allocates because it runs
+ * on the CPU); it is for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  Same arguments, kernels and results (bit for bit) as ptgpu_raycast_batch_dev, but the kernels' scratch memory -- counter
+ * words, the deferred-ray list of deep trees, the stack overflow of a bounded persistent grid -- lives in a fixed 22 MiB device array
+ * inside the library (one copy per GPU, held until the process ends) instead of the context's grow-only buffers, and no hipMalloc /
+ * hipFree / allocating routine is called.  Limits: n <= PTGPU_NOALLOC_MAX_RAYS per call (PTGPU_E_UNSUPPORTED beyond; split the batch);
+ * node-visit / triangle-test counting is not offered and the rays it traces do not show in ptgpu_get_counters.  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (two contexts or streams) race -- serialise them. */
+#define PTGPU_NOALLOC_MAX_RAYS 4194304
+int ptgpu_raycast_batch_dev_noalloc(ptgpu_scene* scene, int use_alpha, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
+                                    int32_t* d_id, float* d_t, float* d_u, float* d_v);
+
 /* Ray generators of BASELINE config 2: pixel-centre primary rays unprojected through invP exactly as
  * src/PathTraceRenderer.cpp:244-266 with the pixel->clip mapping of :716-717, and one shadow ray per primary hit built as
  * :338-344 builds it (origin O + 1e-4 N with N the interpolated vertex normal, direction Pl - O un-normalised) towards the

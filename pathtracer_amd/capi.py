@@ -91,6 +91,7 @@ SIGNATURES = [
     ("ptgpu_scene_stats", C.c_int, [_P, C.POINTER(C.c_uint64 * 4), C.POINTER(C.c_int32)]),
     ("ptgpu_raycast_batch", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
     ("ptgpu_raycast_batch_dev", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    ("ptgpu_raycast_batch_dev_noalloc", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
     ("ptgpu_gen_primary_dev", C.c_int, [_P, C.POINTER(Camera), C.c_int32, C.c_int32, _P, _P]),
     ("ptgpu_gen_shadow_dev", C.c_int, [_P, C.POINTER(Light), C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("ptgpu_render_pass_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -99,6 +100,8 @@ SIGNATURES = [
     ("ptgpu_intersect_triangle1_batch", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
     ("ptgpu_bvh_build_lbvh", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
 ]
+
+NOALLOC_MAX_RAYS = 4194304  # PTGPU_NOALLOC_MAX_RAYS
 
 _lib = None
 
@@ -280,6 +283,10 @@ class Scene:
 
     def raycast_dev(self, d_orig, d_dir, n, occlusion, d_id, d_t, d_u, d_v, use_alpha=True):
         _check(self.lib.ptgpu_raycast_batch_dev(self.handle, int(use_alpha), d_orig, d_dir, n, int(occlusion), d_id, d_t, d_u, d_v))
+
+    def raycast_dev_noalloc(self, d_orig, d_dir, n, occlusion, d_id, d_t, d_u, d_v, use_alpha=True):
+        """The allocation-free variant (fixed scratch inside the library, n <= NOALLOC_MAX_RAYS)."""
+        _check(self.lib.ptgpu_raycast_batch_dev_noalloc(self.handle, int(use_alpha), d_orig, d_dir, n, int(occlusion), d_id, d_t, d_u, d_v))
 
     def gen_shadow_dev(self, light, n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid):
         _check(self.lib.ptgpu_gen_shadow_dev(self.handle, C.byref(light), n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid))

@@ -59,9 +59,23 @@ struct ptgpu_context {
     uint2* d_stack_ovf = nullptr;  // global-memory overflow of the per-lane traversal stacks (trees deeper than the LDS stack)
     size_t stack_ovf_bytes = 0;
     uint2* d_sobol_pairs = nullptr;  // byte-indexed Sobol table for the integrator (pt_integrator.hip.h sobol32x2), built at init
+    unsigned char* scratch = nullptr;  // THIS device's address of the file-scope scratch array (ptgpu_raycast_batch_dev_noalloc)
 };
 constexpr int CTR_WORDS = 32;  // [0..2] public counters, [3..4] spill list, [8..28] diagnostic stamps (PT_STAMPS builds)
 constexpr int SPILL_CAPACITY = 1 << 16;
+
+// What the raycast kernels need beyond their inputs and outputs: counter words, the deferred-ray list of the one-ray-per-lane
+// kernels and the global-memory stack overflow of the persistent ones.  Either the context's grow-only buffers (grow != NULL: sized
+// on demand with hipMalloc) or a fixed region that is never resized (ptgpu_raycast_batch_dev_noalloc).
+struct RcWorkspace {
+    ptgpu_context* grow;            // non-NULL: the buffers below are the context's and may be reallocated larger
+    unsigned long long* counters;   // CTR_WORDS words
+    int32_t* defer;
+    size_t defer_capacity;          // rays
+    uint2* stack_ovf;
+    size_t stack_ovf_bytes;
+    long long max_persist_blocks;   // fixed region only: the persistent grid is clamped to what stack_ovf holds
+};
 
 struct ptgpu_scene {
     ptgpu_context* ctx = nullptr;
@@ -98,6 +112,7 @@ __global__ void k_build_sobol_pairs(uint2* tab) {
 }
 
 extern "C" const char* ptgpu_last_error(void) { return g_err; }
+static int noalloc_scratch_address(unsigned char** out);
 
 extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
     if (!out_ctx) return fail(PTGPU_E_INVALID, "out_ctx is NULL");
@@ -122,6 +137,10 @@ extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
         hipLaunchKernelGGL(k_build_sobol_pairs, dim3((entries + 255) / 256), dim3(256), 0, c->stream, c->d_sobol_pairs);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    {
+        const int rc = noalloc_scratch_address(&c->scratch);  // device `device` is current
+        if (rc != PTGPU_OK) return rc;
     }
     *out_ctx = c;
     return PTGPU_OK;
@@ -517,9 +536,33 @@ static int ensure_stack_overflow(ptgpu_context* c, size_t bytes) {
     c->stack_ovf_bytes = bytes;
     return PTGPU_OK;
 }
+static RcWorkspace context_workspace(ptgpu_context* c) {
+    return RcWorkspace{c, c->d_counters, c->d_defer, c->defer_capacity, c->d_stack_ovf, c->stack_ovf_bytes, 0};
+}
+static int ws_stack_overflow(RcWorkspace& ws, size_t bytes) {
+    if (ws.grow) {
+        int rc = ensure_stack_overflow(ws.grow, bytes);
+        ws.stack_ovf = ws.grow->d_stack_ovf;
+        ws.stack_ovf_bytes = ws.grow->stack_ovf_bytes;
+        return rc;
+    }
+    return bytes <= ws.stack_ovf_bytes ? PTGPU_OK : fail(PTGPU_E_UNSUPPORTED, "fixed workspace: %zu bytes of stack overflow needed, %zu available", bytes, ws.stack_ovf_bytes);
+}
+static int ws_defer_list(RcWorkspace& ws, size_t n) {
+    if (n <= ws.defer_capacity) return PTGPU_OK;
+    if (!ws.grow) return fail(PTGPU_E_UNSUPPORTED, "fixed workspace: deferred-ray list holds %zu rays, %zu needed", ws.defer_capacity, n);
+    ptgpu_context* c = ws.grow;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_defer) { HIP_TRY(hipFree(c->d_defer)); c->d_defer = nullptr; c->defer_capacity = 0; }
+    HIP_TRY(hipMalloc(&c->d_defer, n * sizeof(int32_t)));
+    c->defer_capacity = n;
+    ws.defer = c->d_defer;
+    ws.defer_capacity = n;
+    return PTGPU_OK;
+}
 
 template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
-static int launch_rc_persist(ptgpu_scene* s, const ptd::TravScene& trav, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v,
+static int launch_rc_persist(ptgpu_scene* s, RcWorkspace& ws, const ptd::TravScene& trav, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v,
                              const int32_t* ray_index = nullptr, long long expected = -1) {
     ptgpu_context* c = s->ctx;
     long long want = ((expected >= 0 ? expected : n) + RC_CHUNK - 1) / RC_CHUNK;  // no more waves than chunks
@@ -536,17 +579,18 @@ static int launch_rc_persist(ptgpu_scene* s, const ptd::TravScene& trav, const f
     }
     long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_RAYCAST_OVERSUB", 1);
     if (blocks > resident) blocks = resident;
+    if (!ws.grow && blocks > ws.max_persist_blocks) blocks = ws.max_persist_blocks;
     if (OVF) {
-        int rc = ensure_stack_overflow(c, (size_t)blocks * (RC_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
+        int rc = ws_stack_overflow(ws, (size_t)blocks * (RC_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
         if (rc != PTGPU_OK) return rc;
     }
     hipLaunchKernelGGL((k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(RC_BLOCK), 0, c->stream, trav, o, d, n, id, t,
-                       u, v, c->d_counters, env_int("PTGPU_RAYCAST_REFILL", 32), c->d_stack_ovf, ray_index);
+                       u, v, ws.counters, env_int("PTGPU_RAYCAST_REFILL", 32), ws.stack_ovf, ray_index);
     return PTGPU_OK;
 }
 
 template <bool ANYHIT, bool ALPHA, bool COUNT>
-static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
+static int launch_raycast(ptgpu_scene* s, RcWorkspace& ws, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v) {
     ptgpu_context* c = s->ctx;
     ptd::TravScene trav = s->trav;
     trav.alpha_on = ALPHA ? 1 : 0;
@@ -560,34 +604,49 @@ static int launch_raycast(ptgpu_scene* s, const float* o, const float* d, long l
     const bool small_scene = s->bytes[0] + s->bytes[1] <= (4u << 20) && need <= 24;
     const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : (need <= 24 ? 12 : 16));
     if constexpr (COUNT || ALPHA) {  // rare variants: one configuration that is valid for every depth
-        return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
+        return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, ws, trav, o, d, n, id, t, u, v);
     } else {
         if (impl == 2) {
-            if (need > 24 || (need > 16 && nlds == 16)) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v);
-            return nlds == 16 ? launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, false>(s, trav, o, d, n, id, t, u, v)
-                              : launch_rc_persist<ANYHIT, ALPHA, COUNT, 24, false>(s, trav, o, d, n, id, t, u, v);
+            if (need > 24 || (need > 16 && nlds == 16)) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, ws, trav, o, d, n, id, t, u, v);
+            return nlds == 16 ? launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, false>(s, ws, trav, o, d, n, id, t, u, v)
+                              : launch_rc_persist<ANYHIT, ALPHA, COUNT, 24, false>(s, ws, trav, o, d, n, id, t, u, v);
         }
         // one ray per lane.  If the tree could need more stack than the LDS holds, rays that actually do are deferred to a
         // second, persistent launch with global-memory overflow (they are rare: occupancy stays < 16 for almost every ray).
         const bool defer = need > nlds;
         if (defer) {
             if (n > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large for the deferred-ray list");
-            if ((size_t)n > c->defer_capacity) {
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                if (c->d_defer) { HIP_TRY(hipFree(c->d_defer)); c->d_defer = nullptr; c->defer_capacity = 0; }
-                HIP_TRY(hipMalloc(&c->d_defer, (size_t)n * sizeof(int32_t)));
-                c->defer_capacity = (size_t)n;
-            }
-            hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + 5, 1);
+            const int rc = ws_defer_list(ws, (size_t)n);
+            if (rc != PTGPU_OK) return rc;
+            hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, ws.counters + 5, 1);
         }
-        ptd::launch_raycast_step(ANYHIT, nlds, defer, c->stream, trav, o, d, n, id, t, u, v, c->d_counters, c->d_defer);
+        ptd::launch_raycast_step(ANYHIT, nlds, defer, c->stream, trav, o, d, n, id, t, u, v, ws.counters, ws.defer);
         if (defer) {
             // the number of deferred rays is only known on the device: a small fixed grid, the kernel reads the count itself
             const long long expected = n / 64 < 65536 ? 65536 : n / 64;
-            return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, trav, o, d, n, id, t, u, v, c->d_defer, expected < n ? expected : n);
+            return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, ws, trav, o, d, n, id, t, u, v, ws.defer, expected < n ? expected : n);
         }
         return PTGPU_OK;
     }
+}
+
+static int raycast_dispatch(ptgpu_scene* s, RcWorkspace& ws, bool alpha, bool count, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
+                            int32_t* d_id, float* d_t, float* d_u, float* d_v) {
+    int rc;
+    const int sel = (occlusion ? 4 : 0) | (alpha ? 2 : 0) | (count ? 1 : 0);
+    switch (sel) {
+        case 0: rc = launch_raycast<false, false, false>(s, ws, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 1: rc = launch_raycast<false, false, true>(s, ws, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 2: rc = launch_raycast<false, true, false>(s, ws, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 3: rc = launch_raycast<false, true, true>(s, ws, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 4: rc = launch_raycast<true, false, false>(s, ws, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 5: rc = launch_raycast<true, false, true>(s, ws, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        case 6: rc = launch_raycast<true, true, false>(s, ws, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+        default: rc = launch_raycast<true, true, true>(s, ws, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
+    }
+    if (rc != PTGPU_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
 }
 
 extern "C" int ptgpu_raycast_batch_dev(ptgpu_scene* s, int use_alpha, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
@@ -598,22 +657,56 @@ extern "C" int ptgpu_raycast_batch_dev(ptgpu_scene* s, int use_alpha, const floa
     if (!d_orig || !d_dir) return fail(PTGPU_E_INVALID, "ray arrays are NULL");
     if ((n + RC_STEP_BLOCK - 1) / RC_STEP_BLOCK > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large for one launch");
     HIP_TRY(hipSetDevice(s->ctx->device));
-    const bool alpha = use_alpha && s->has_alpha, count = s->ctx->count;
-    int rc;
-    const int sel = (occlusion ? 4 : 0) | (alpha ? 2 : 0) | (count ? 1 : 0);
-    switch (sel) {
-        case 0: rc = launch_raycast<false, false, false>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
-        case 1: rc = launch_raycast<false, false, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
-        case 2: rc = launch_raycast<false, true, false>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
-        case 3: rc = launch_raycast<false, true, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
-        case 4: rc = launch_raycast<true, false, false>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
-        case 5: rc = launch_raycast<true, false, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
-        case 6: rc = launch_raycast<true, true, false>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
-        default: rc = launch_raycast<true, true, true>(s, d_orig, d_dir, n, d_id, d_t, d_u, d_v); break;
-    }
-    if (rc != PTGPU_OK) return rc;
-    HIP_TRY(hipGetLastError());
+    RcWorkspace ws = context_workspace(s->ctx);
+    return raycast_dispatch(s, ws, use_alpha && s->has_alpha, s->ctx->count, d_orig, d_dir, n, occlusion, d_id, d_t, d_u, d_v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The entry point that allocates nothing (include/ptgpu.h): ptgpu_raycast_batch_dev's kernels with their scratch memory -- counter
+// words, deferred-ray list, stack overflow of a bounded persistent grid -- in a file-scope device array instead of the context's
+// grow-only hipMalloc buffers.  The array's name is only a host-side handle: its device address is taken once per device in
+// ptgpu_init (hipGetSymbolAddress with that device current) and kept in the context; every GPU holds its own copy.
+// ------------------------------------------------------------------------------------------------
+constexpr long long NOALLOC_MAX_RAYS = PTGPU_NOALLOC_MAX_RAYS;
+constexpr long long NOALLOC_PERSIST_BLOCKS = 64;  // x 4 waves x 24 KiB of overflow stack = 6 MiB
+constexpr size_t NOALLOC_OFF_DEFER = 256 * sizeof(unsigned long long);  // counter words first (CTR_WORDS of them used)
+constexpr size_t NOALLOC_OFF_STACK = NOALLOC_OFF_DEFER + (size_t)NOALLOC_MAX_RAYS * sizeof(int32_t);
+constexpr size_t NOALLOC_STACK_BYTES = (size_t)NOALLOC_PERSIST_BLOCKS * (RC_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<16>();
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_OFF_STACK + NOALLOC_STACK_BYTES;
+static_assert(CTR_WORDS <= 256 && NOALLOC_OFF_DEFER % 256 == 0 && NOALLOC_OFF_STACK % 256 == 0, "scratch regions stay 256-byte aligned");
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+// once per device, from ptgpu_init with that device current
+static int noalloc_scratch_address(unsigned char** out) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(PTGPU_E_HIP, "hipGetSymbolAddress returned a NULL scratch address");
+    *out = static_cast<unsigned char*>(p);
     return PTGPU_OK;
+}
+
+extern "C" int ptgpu_raycast_batch_dev_noalloc(ptgpu_scene* s, int use_alpha, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
+                                               int32_t* d_id, float* d_t, float* d_u, float* d_v) {
+    if (!s) return fail(PTGPU_E_INVALID, "scene is NULL");
+    if (n < 0) return fail(PTGPU_E_INVALID, "n < 0");
+    if (n > NOALLOC_MAX_RAYS)
+        return fail(PTGPU_E_UNSUPPORTED, "ptgpu_raycast_batch_dev_noalloc takes at most %lld rays per call (got %lld): split the batch or use ptgpu_raycast_batch_dev",
+                    NOALLOC_MAX_RAYS, (long long)n);
+    if (n == 0) return PTGPU_OK;
+    if (!d_orig || !d_dir) return fail(PTGPU_E_INVALID, "ray arrays are NULL");
+    ptgpu_context* c = s->ctx;
+    if (!c->scratch) return fail(PTGPU_E_HIP, "the context has no scratch address (ptgpu_init did not complete)");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned char* base = c->scratch;  // the device address, never the array's name
+    RcWorkspace ws{nullptr,
+                   reinterpret_cast<unsigned long long*>(base),
+                   reinterpret_cast<int32_t*>(base + NOALLOC_OFF_DEFER), (size_t)NOALLOC_MAX_RAYS,
+                   reinterpret_cast<uint2*>(base + NOALLOC_OFF_STACK), NOALLOC_STACK_BYTES,
+                   NOALLOC_PERSIST_BLOCKS};
+    // The scratch keeps the last call's contents.  What must start at zero is the deferred-ray count (word 5), cleared by the launcher
+    // before every deferring launch; list entries and stack slots are written before they are read.  Counting variants are not
+    // offered here (the context's counters live in allocated memory): rays traced by this entry point do not show in ptgpu_get_counters.
+    return raycast_dispatch(s, ws, use_alpha && s->has_alpha, false, d_orig, d_dir, n, occlusion, d_id, d_t, d_u, d_v);
 }
 
 extern "C" int ptgpu_raycast_batch(ptgpu_scene* s, int use_alpha, const float* orig, const float* dir, int64_t n, int occlusion,
