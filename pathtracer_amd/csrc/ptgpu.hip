@@ -59,6 +59,8 @@ struct ptgpu_context {
     uint2* d_stack_ovf = nullptr;  // global-memory overflow of the per-lane traversal stacks (trees deeper than the LDS stack)
     size_t stack_ovf_bytes = 0;
     uint2* d_sobol_pairs = nullptr;  // byte-indexed Sobol table for the integrator (pt_integrator.hip.h sobol32x2), built at init
+    unsigned char* d_stage = nullptr;  // grow-only device staging of the host-pointer entry points (rays in, hit records out, images)
+    size_t stage_bytes = 0;
     unsigned char* scratch = nullptr;  // THIS device's address of the file-scope scratch array (ptgpu_raycast_batch_dev_noalloc)
 };
 constexpr int CTR_WORDS = 32;  // [0..2] public counters, [3..4] spill list, [8..28] diagnostic stamps (PT_STAMPS builds)
@@ -113,6 +115,21 @@ __global__ void k_build_sobol_pairs(uint2* tab) {
 
 extern "C" const char* ptgpu_last_error(void) { return g_err; }
 static int noalloc_scratch_address(unsigned char** out);
+extern "C" int ptgpu_shutdown(ptgpu_context* c);
+
+static int init_context(ptgpu_context* c, const hipDeviceProp_t& prop) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipMalloc(&c->d_counters, CTR_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_counters, 0, CTR_WORDS * sizeof(unsigned long long)));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int entries = ptd::SOBOL_PAIRS * 3 * 256;
+    HIP_TRY(hipMalloc(&c->d_sobol_pairs, (size_t)entries * sizeof(uint2)));
+    hipLaunchKernelGGL(k_build_sobol_pairs, dim3((entries + 255) / 256), dim3(256), 0, c->stream, c->d_sobol_pairs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return noalloc_scratch_address(&c->scratch);  // device `device` is current
+}
 
 extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
     if (!out_ctx) return fail(PTGPU_E_INVALID, "out_ctx is NULL");
@@ -126,21 +143,13 @@ extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
         return fail(PTGPU_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     ptgpu_context* c = new ptgpu_context();
     c->device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    HIP_TRY(hipMalloc(&c->d_counters, CTR_WORDS * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_counters, 0, CTR_WORDS * sizeof(unsigned long long)));
-    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    {
-        const int entries = ptd::SOBOL_PAIRS * 3 * 256;
-        HIP_TRY(hipMalloc(&c->d_sobol_pairs, (size_t)entries * sizeof(uint2)));
-        hipLaunchKernelGGL(k_build_sobol_pairs, dim3((entries + 255) / 256), dim3(256), 0, c->stream, c->d_sobol_pairs);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    {
-        const int rc = noalloc_scratch_address(&c->scratch);  // device `device` is current
-        if (rc != PTGPU_OK) return rc;
+    const int rc = init_context(c, prop);
+    if (rc != PTGPU_OK) {  // free what was set up, keep the message of the call that failed
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        ptgpu_shutdown(c);
+        memcpy(g_err, keep, sizeof keep);
+        return rc;
     }
     *out_ctx = c;
     return PTGPU_OK;
@@ -149,7 +158,8 @@ extern "C" int ptgpu_init(int device, ptgpu_context** out_ctx) {
 extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     if (!c) return PTGPU_OK;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->d_stage) hipFree(c->d_stage);
     if (c->d_counters) hipFree(c->d_counters);
     if (c->d_rad) hipFree(c->d_rad);
     if (c->d_lights) hipFree(c->d_lights);
@@ -536,6 +546,15 @@ static int ensure_stack_overflow(ptgpu_context* c, size_t bytes) {
     c->stack_ovf_bytes = bytes;
     return PTGPU_OK;
 }
+// device staging for the entry points that take HOST pointers: grown when a call needs more, never shrunk, freed at shutdown
+static int ensure_stage(ptgpu_context* c, size_t bytes) {
+    if (bytes <= c->stage_bytes) return PTGPU_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_stage) { HIP_TRY(hipFree(c->d_stage)); c->d_stage = nullptr; c->stage_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return PTGPU_OK;
+}
 static RcWorkspace context_workspace(ptgpu_context* c) {
     return RcWorkspace{c, c->d_counters, c->d_defer, c->defer_capacity, c->d_stack_ovf, c->stack_ovf_bytes, 0};
 }
@@ -603,6 +622,8 @@ static int launch_raycast(ptgpu_scene* s, RcWorkspace& ws, const float* o, const
     // 16: 2.14/2.03, 24: 2.73/2.56.
     const bool small_scene = s->bytes[0] + s->bytes[1] <= (4u << 20) && need <= 24;
     const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : (need <= 24 ? 12 : 16));
+    if (nlds != 8 && nlds != 12 && nlds != 16 && nlds != 24)  // the instantiated set: `defer` below must describe the kernel that runs
+        return fail(PTGPU_E_INVALID, "PTGPU_RAYCAST_NLDS=%d: the LDS stack is built with 8, 12, 16 or 24 entries", nlds);
     if constexpr (COUNT || ALPHA) {  // rare variants: one configuration that is valid for every depth
         return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, ws, trav, o, d, n, id, t, u, v);
     } else {
@@ -715,29 +736,29 @@ extern "C" int ptgpu_raycast_batch(ptgpu_scene* s, int use_alpha, const float* o
     if (n < 0) return fail(PTGPU_E_INVALID, "n < 0");
     if (n == 0) return PTGPU_OK;
     if (!orig || !dir) return fail(PTGPU_E_INVALID, "ray arrays are NULL");
-    HIP_TRY(hipSetDevice(s->ctx->device));
-    hipStream_t st = s->ctx->stream;
-    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_u = nullptr, *d_v = nullptr;
-    int32_t* d_id = nullptr;
-    int rc = PTGPU_OK;
-    auto cleanup = [&]() { for (void* p : {(void*)d_o, (void*)d_d, (void*)d_t, (void*)d_u, (void*)d_v, (void*)d_id}) if (p) hipFree(p); };
-#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(PTGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    TRY2(hipMalloc(&d_o, n * 12)); TRY2(hipMalloc(&d_d, n * 12));
-    if (out_id) TRY2(hipMalloc(&d_id, n * 4));
-    if (out_t) TRY2(hipMalloc(&d_t, n * 4));
-    if (out_u) TRY2(hipMalloc(&d_u, n * 4));
-    if (out_v) TRY2(hipMalloc(&d_v, n * 4));
-    TRY2(hipMemcpyAsync(d_o, orig, n * 12, hipMemcpyHostToDevice, st));
-    TRY2(hipMemcpyAsync(d_d, dir, n * 12, hipMemcpyHostToDevice, st));
+    ptgpu_context* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // one grow-only staging buffer: origins, directions, then the four output arrays (a single-ray call of the reference-signature
+    // RayTracer::raycast() allocates nothing after the first)
+    const size_t N = (size_t)n, slot = (N * 4 + 255) & ~(size_t)255, slot3 = (N * 12 + 255) & ~(size_t)255;
+    int rc = ensure_stage(c, 2 * slot3 + 4 * slot);
+    if (rc != PTGPU_OK) return rc;
+    unsigned char* b = c->d_stage;
+    float *d_o = (float*)b, *d_d = (float*)(b + slot3);
+    int32_t* d_id = out_id ? (int32_t*)(b + 2 * slot3) : nullptr;
+    float* d_t = out_t ? (float*)(b + 2 * slot3 + slot) : nullptr;
+    float* d_u = out_u ? (float*)(b + 2 * slot3 + 2 * slot) : nullptr;
+    float* d_v = out_v ? (float*)(b + 2 * slot3 + 3 * slot) : nullptr;
+    HIP_TRY(hipMemcpyAsync(d_o, orig, N * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_d, dir, N * 12, hipMemcpyHostToDevice, st));
     rc = ptgpu_raycast_batch_dev(s, use_alpha, d_o, d_d, n, occlusion, d_id, d_t, d_u, d_v);
-    if (rc != PTGPU_OK) { cleanup(); return rc; }
-    if (out_id) TRY2(hipMemcpyAsync(out_id, d_id, n * 4, hipMemcpyDeviceToHost, st));
-    if (out_t) TRY2(hipMemcpyAsync(out_t, d_t, n * 4, hipMemcpyDeviceToHost, st));
-    if (out_u) TRY2(hipMemcpyAsync(out_u, d_u, n * 4, hipMemcpyDeviceToHost, st));
-    if (out_v) TRY2(hipMemcpyAsync(out_v, d_v, n * 4, hipMemcpyDeviceToHost, st));
-    TRY2(hipStreamSynchronize(st));
-#undef TRY2
-    cleanup();
+    if (rc != PTGPU_OK) return rc;
+    if (out_id) HIP_TRY(hipMemcpyAsync(out_id, d_id, N * 4, hipMemcpyDeviceToHost, st));
+    if (out_t) HIP_TRY(hipMemcpyAsync(out_t, d_t, N * 4, hipMemcpyDeviceToHost, st));
+    if (out_u) HIP_TRY(hipMemcpyAsync(out_u, d_u, N * 4, hipMemcpyDeviceToHost, st));
+    if (out_v) HIP_TRY(hipMemcpyAsync(out_v, d_v, N * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return PTGPU_OK;
 }
 
@@ -1101,17 +1122,14 @@ extern "C" int ptgpu_render_pass(ptgpu_scene* s, const ptgpu_params* prm, const 
     ptgpu_context* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)prm->width * prm->height * 16;
-    float* d = nullptr;
-    HIP_TRY(hipMalloc(&d, bytes));
-    hipError_t e = hipMemcpyAsync(d, accum, bytes, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        rc = ptgpu_render_pass_dev(s, prm, cam, lights, num_lights, block_begin, block_end, block_stride, d);
-        if (rc == PTGPU_OK) e = hipMemcpyAsync(accum, d, bytes, hipMemcpyDeviceToHost, c->stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
+    rc = ensure_stage(c, bytes);
     if (rc != PTGPU_OK) return rc;
-    if (e != hipSuccess) return fail(PTGPU_E_HIP, "render pass: %s", hipGetErrorString(e));
+    float* d = reinterpret_cast<float*>(c->d_stage);
+    HIP_TRY(hipMemcpyAsync(d, accum, bytes, hipMemcpyHostToDevice, c->stream));
+    rc = ptgpu_render_pass_dev(s, prm, cam, lights, num_lights, block_begin, block_end, block_stride, d);
+    if (rc != PTGPU_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(accum, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     unsigned long long ovf = 0;
     HIP_TRY(hipMemcpy(&ovf, c->d_counters + 4, sizeof ovf, hipMemcpyDeviceToHost));
     if (ovf) return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples did not fit the spill list", ovf);

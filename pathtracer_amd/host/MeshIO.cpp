@@ -75,6 +75,13 @@ std::unique_ptr<MeshWithColors> importPtMesh(const std::string& path, std::strin
     f.read((char*)hdr, 16);
     if (!f || std::memcmp(magic, "PTMESH1\0", 8) != 0 || hdr[0] < 0 || hdr[1] < 0 || hdr[2] <= 0) { fail(err, path + ": bad .ptmesh header"); return nullptr; }
     const int nv = hdr[0], nt = hdr[1], nm = hdr[2];
+    {   // the header's counts must fit the file before anything is sized from them
+        f.seekg(0, std::ios::end);
+        const long long fileBytes = (long long)f.tellg();
+        f.seekg(24, std::ios::beg);
+        const long long need = 24 + 32LL * nv + 16LL * nt + 192LL * nm;  // 8 floats per vertex, 3 + 1 ints per triangle, 192-byte material records
+        if (need > fileBytes) { fail(err, path + ": header counts exceed the file's size"); return nullptr; }
+    }
     std::vector<float> pos((size_t)nv * 3), nrm((size_t)nv * 3), uv((size_t)nv * 2);
     std::vector<int32_t> idx((size_t)nt * 3), tmat(nt);
     f.read((char*)pos.data(), pos.size() * 4); f.read((char*)nrm.data(), nrm.size() * 4); f.read((char*)uv.data(), uv.size() * 4);

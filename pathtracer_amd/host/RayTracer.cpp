@@ -81,7 +81,7 @@ void RayTracer::saveHierarchy(const char* filename, const std::vector<RTTriangle
     for (const FlatNode& n : bvh.nodes) {
         put(f, n.box.min); put(f, n.box.max);
         put(f, n.startIdx); put(f, n.endIdx); put(f, n.rightChild);
-        put(f, n.leaf);
+        put(f, (uint8_t)(n.leaf ? 1 : 0));
         put(f, n.axis);
     }
     put(f, bvh.depth);
@@ -90,25 +90,28 @@ void RayTracer::saveHierarchy(const char* filename, const std::vector<RTTriangle
 void RayTracer::loadHierarchy(const char* filename, std::vector<RTTriangle>& triangles) {
     m_triangles = &triangles;
     std::ifstream f(filename, std::ios::binary);
+    if (!f) throw GpuError(std::string("loadHierarchy: cannot open ") + filename);
+    f.seekg(0, std::ios::end);
+    const long long fileBytes = (long long)f.tellg();
+    f.seekg(0, std::ios::beg);
+    auto bad = [&](const char* what) { return GpuError(std::string("loadHierarchy: ") + filename + ": " + what); };
     int32_t listSize = 0, nNodes = 0, depth = 0;
-    std::vector<int32_t> list;
+    // counts are checked against the file's length before anything is sized from them
+    if (!get(f, listSize) || listSize < 0 || 4LL * listSize > fileBytes) throw bad("bad list size");
+    std::vector<int32_t> list((size_t)listSize);
+    if (listSize && !f.read(reinterpret_cast<char*>(list.data()), (std::streamsize)listSize * 4)) throw bad("truncated index list");
+    if (!get(f, nNodes) || nNodes < 0 || 41LL * nNodes > fileBytes) throw bad("bad node count");
     std::vector<FlatNode> nodes;
-    if (get(f, listSize) && listSize >= 0) {
-        list.resize(listSize);
-        for (int32_t& v : list) get(f, v);
-        if (get(f, nNodes) && nNodes >= 0) {
-            nodes.reserve(nNodes);
-            for (int32_t i = 0; i < nNodes; ++i) {
-                Vec3f mn, mx;
-                int32_t s = 0, e = 0, r = 0, ax = 0;
-                bool leaf = false;
-                get(f, mn); get(f, mx); get(f, s); get(f, e); get(f, r); get(f, leaf); get(f, ax);
-                nodes.emplace_back(AABB(mn, mx), s, e, r, leaf, ax);
-                if (!leaf) nodes.back().leftChild = i + 1;
-            }
-            get(f, depth);
-        }
+    nodes.reserve((size_t)nNodes);
+    for (int32_t i = 0; i < nNodes; ++i) {
+        Vec3f mn, mx;
+        int32_t s = 0, e = 0, r = 0, ax = 0;
+        uint8_t leaf = 0;  // the reference writes its bool as one byte (:156); any non-zero value reads as a leaf
+        if (!(get(f, mn) && get(f, mx) && get(f, s) && get(f, e) && get(f, r) && get(f, leaf) && get(f, ax))) throw bad("truncated node array");
+        nodes.emplace_back(AABB(mn, mx), s, e, r, leaf != 0, ax);
+        if (!leaf) nodes.back().leftChild = i + 1;
     }
+    if (!get(f, depth)) throw bad("missing depth field");
     bvh = BVH(m_triangles, list, nodes, depth);
     invalidateDeviceScene();
 }
