@@ -205,6 +205,36 @@ int ptgpu_render_pass(ptgpu_scene* scene, const ptgpu_params* params, const ptgp
  * pixels pass through undivided.  Both pointers are DEVICE pointers, [height][width][4] floats. */
 int ptgpu_resolve_dev(ptgpu_context* ctx, const float* d_accum, int32_t width, int32_t height, float* d_out_rgba);
 
+/* Out-of-block samples of the LAST Sobol-block pass on this context (a sample whose sobol() coordinate rounds to exactly 1.0f lands one
+ * pixel outside its block, src/PathTraceRenderer.cpp:714-728, p = 2^-24 per coordinate): out[0] = how many there were, out[1] = how many
+ * were DROPPED because a list was full (0 in any sane render; ptgpu_render_pass reports it as an error, callers of the _dev variant
+ * ask here), out[2] = entries waiting in the foreign list (samples that landed in a block of another rank, delivered by
+ * ptgpu_gather_tiles_dev / ptgpu_tiles_pack_dev).  Synchronises the context's stream. */
+int ptgpu_spill_status(ptgpu_context* ctx, uint64_t out[3]);
+
+/* ---- image tiles across the GPUs of one node (one process and one context per GPU).  No counterpart in the reference, whose worker
+ * threads write disjoint 32x32 blocks of ONE shared image (src/PathTraceRenderer.cpp:727-732, :785-787, blocks built at :816-841); here
+ * rank r of N renders blocks r, r+N, ... (ptgpu_render_pass_dev with block_begin = r, block_stride = N) into its own full-size
+ * accumulation image and, after a pass, ptgpu_gather_tiles_dev fills in every other rank's blocks with ONE all-gather over RCCL (xGMI).
+ * Nothing is summed: the N-GPU image equals the 1-GPU image bit for bit, including samples that land one pixel outside their block in
+ * another rank's tile (they travel in a small fixed section of each rank's slice and are added, in rank order, on every rank).
+ *
+ * ptgpu_comm_create_id: rank 0 makes a PTGPU_COMM_ID_BYTES id (an ncclUniqueId) and hands it to the other ranks by any means (file,
+ * environment, MPI, a torch.distributed broadcast).  ptgpu_comm_init: collective over all ranks (ncclCommInitRank on the context's
+ * device); the communicator belongs to the context and is destroyed with it or by ptgpu_comm_destroy.  RCCL is loaded on first use.
+ * ptgpu_gather_tiles_dev: enqueued on the context's stream after the pass; all ranks end with the full image in d_accum. */
+#define PTGPU_COMM_ID_BYTES 128
+int ptgpu_comm_create_id(void* out_id);
+int ptgpu_comm_init(ptgpu_context* ctx, int32_t world, int32_t rank, const void* id);
+int ptgpu_comm_destroy(ptgpu_context* ctx);
+int ptgpu_gather_tiles_dev(ptgpu_context* ctx, int32_t width, int32_t height, float* d_accum);
+/* The two halves of the gather for callers that bring their own transport (MPI, torch.distributed, a host relay): pack this rank's
+ * blocks and pending foreign samples into one slice of ptgpu_tiles_slice_floats() floats; exchange so that d_slices holds the world
+ * slices in rank order; unpack writes the other ranks' blocks into d_accum and adds every rank's foreign samples. */
+int ptgpu_tiles_slice_floats(int32_t width, int32_t height, int32_t world, int64_t* out_floats);
+int ptgpu_tiles_pack_dev(ptgpu_context* ctx, int32_t width, int32_t height, int32_t world, int32_t rank, const float* d_accum, float* d_slice);
+int ptgpu_tiles_unpack_dev(ptgpu_context* ctx, int32_t width, int32_t height, int32_t world, int32_t rank, const float* d_slices, float* d_accum);
+
 /* Optional device-side BVH builder (no counterpart in the reference, whose builders are the CPU SAH sweep and
  * median splits of src/Bvh.cpp:98-234, constructed by BVH::BVH(triangles, sahEnabled), src/Bvh.cpp:11-42): a linear BVH over 63-bit
  * Morton codes, emitted in the reference's FlatNode layout (src/BvhNode.hpp:67-113; pre-order, left child = index + 1, src/Bvh.cpp:70-96)

@@ -2,6 +2,7 @@
 // C ABI over pt_core.h / pt_bvh.cpp; multi-threaded over rays / 32x32 blocks for the
 // cpu_baseline leg of bench.py (same block tiling as reference src/PathTraceRenderer.cpp:816-852).
 #include <atomic>
+#include <cstring>
 #include <thread>
 
 #include "pt_core.h"
@@ -185,21 +186,51 @@ void pto_gen_shadow(const pto_scene* s, const pto_light* l, int64_t n, const flo
     }
 }
 
-void pto_render_pass(const pto_scene* s, const pto_params* p, const pto_camera* cam, const pto_light* lights, int nl,
-                     float* accum, pto_counters* ctr, int nthreads, int libm, int block_begin, int block_end) {
+// One pass over blocks block_begin, block_begin + block_stride, ... < block_end.  Out-of-block samples are applied after every block is
+// done, in (block, sample) order: to accum when their pixel lies in one of this call's blocks, else appended to foreign_out
+// (8 floats each: r g b w, pixel as int bits, 3 pad -- the device's ForeignSpill) when given, else to accum as well.
+void pto_render_pass2(const pto_scene* s, const pto_params* p, const pto_camera* cam, const pto_light* lights, int nl,
+                      float* accum, pto_counters* ctr, int nthreads, int libm, int block_begin, int block_end, int block_stride,
+                      float* foreign_out, int foreign_cap, int* foreign_count) {
     std::vector<Block> blocks = make_blocks(p->width, p->height);
     if (block_end < 0 || block_end > (int)blocks.size()) block_end = (int)blocks.size();
     if (block_begin < 0) block_begin = 0;
+    if (block_stride < 1) block_stride = 1;
     if (nthreads < 1) nthreads = 1;
+    const int count = block_end > block_begin ? (block_end - block_begin + block_stride - 1) / block_stride : 0;
     std::vector<Counters> c(nthreads);
-    parallel_for(block_end - block_begin, 1, nthreads, [&](int64_t b, int64_t e, int t) {
+    std::vector<std::vector<Spill>> spills(count);
+    parallel_for(count, 1, nthreads, [&](int64_t b, int64_t e, int t) {
         for (int64_t i = b; i < e; ++i) {
-            int idx = block_begin + (int)i;
-            if (libm) path_trace_block<LibmMath>(*s, *p, *cam, lights, nl, idx, blocks[idx], accum, c[t]);
-            else path_trace_block<PtmMath>(*s, *p, *cam, lights, nl, idx, blocks[idx], accum, c[t]);
+            int idx = block_begin + (int)i * block_stride;
+            if (libm) path_trace_block<LibmMath>(*s, *p, *cam, lights, nl, idx, blocks[idx], accum, c[t], &spills[i]);
+            else path_trace_block<PtmMath>(*s, *p, *cam, lights, nl, idx, blocks[idx], accum, c[t], &spills[i]);
         }
     });
+    const int blocks_x = (p->width + 31) / 32;
+    int nf = 0;
+    for (const auto& list : spills)
+        for (const Spill& sp : list) {
+            const int idx = ((sp.pixel / p->width) >> 5) * blocks_x + ((sp.pixel % p->width) >> 5);
+            const bool own = idx >= block_begin && idx < block_end && (idx - block_begin) % block_stride == 0;
+            if (own || !foreign_out) {
+                float* px = accum + (size_t)sp.pixel * 4;
+                px[0] += sp.r; px[1] += sp.g; px[2] += sp.b; px[3] += sp.w;
+            } else if (nf < foreign_cap) {
+                float* o = foreign_out + (size_t)nf * 8;
+                o[0] = sp.r; o[1] = sp.g; o[2] = sp.b; o[3] = sp.w;
+                std::memcpy(o + 4, &sp.pixel, 4);
+                o[5] = o[6] = o[7] = 0.0f;
+                ++nf;
+            }
+        }
+    if (foreign_count) *foreign_count = nf;
     add_counters(ctr, c);
+}
+
+void pto_render_pass(const pto_scene* s, const pto_params* p, const pto_camera* cam, const pto_light* lights, int nl,
+                     float* accum, pto_counters* ctr, int nthreads, int libm, int block_begin, int block_end) {
+    pto_render_pass2(s, p, cam, lights, nl, accum, ctr, nthreads, libm, block_begin, block_end, 1, nullptr, 0, nullptr);
 }
 
 // reference src/PathTraceRenderer.cpp:855-871

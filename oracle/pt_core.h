@@ -516,9 +516,15 @@ inline int block_sobol_base(int idx, uint32_t pass_seed) {
 // reference src/PathTraceRenderer.cpp:663-790, one block.  The reference threads ONE Random
 // through all samples of a block; this build gives every sample its own stream keyed by
 // (block, pass_seed, i, k) (documented deviation, SURVEY.md 7 "Sequential RNG").
+// A Sobol-block sample whose pixel lies outside its own block (sobol() rounds to exactly 1.0f): the reference's worker
+// thread adds it to the neighbouring block's pixel while another thread may be working on that block (a race).  This build defers
+// such samples to the end of the pass (device: k_apply_spill) and, with image tiles sharded over ranks, hands those that fall in
+// another rank's block to that rank (device: ptgpu_tiles_pack_dev); `spills` collects them in sample order.
+struct Spill { float r, g, b, w; int pixel; };
+
 template <class Mth>
 inline void path_trace_block(const pto_scene& s, const pto_params& prm, const pto_camera& cam, const pto_light* lights, int nl,
-                             int idx, const Block& block, float* accum, Counters& ctr) {
+                             int idx, const Block& block, float* accum, Counters& ctr, std::vector<Spill>* spills = nullptr) {
     int base = block_sobol_base(idx, prm.pass_seed);
     int height = prm.height, width = prm.width;
     float div_x = 1.0f / (float)width, div_y = 1.0f / (float)height;
@@ -535,6 +541,11 @@ inline void path_trace_block(const pto_scene& s, const pto_params& prm, const pt
                                    : trace_path<Mth>(s, prm, cam, lights, nl, x, y, base + i, R, ctr);
             int pixel_x = (int)std::floor(px); if (pixel_x > width - 1) pixel_x = width - 1;
             int pixel_y = (int)std::floor(py); if (pixel_y > height - 1) pixel_y = height - 1;
+            if (spills && (pixel_x < block.x || pixel_x >= block.x + block.w || pixel_y < block.y || pixel_y >= block.y + block.h)) {
+                spills->push_back(Spill{color.x * scaleToAaRays, color.y * scaleToAaRays, color.z * scaleToAaRays, 1.0f * scaleToAaRays,
+                                        pixel_y * width + pixel_x});
+                continue;
+            }
             float* prev = accum + ((size_t)pixel_y * width + pixel_x) * 4;
             prev[0] += color.x * scaleToAaRays;
             prev[1] += color.y * scaleToAaRays;

@@ -50,6 +50,9 @@ def lib():
         L.pto_gen_shadow.argtypes = [C.POINTER(SceneDesc), C.POINTER(Light), C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]
         L.pto_render_pass.argtypes = [C.POINTER(SceneDesc), C.POINTER(Params), C.POINTER(Camera), _P, C.c_int, _P,
                                       C.POINTER(Counters), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.pto_render_pass2.argtypes = [C.POINTER(SceneDesc), C.POINTER(Params), C.POINTER(Camera), _P, C.c_int, _P,
+                                       C.POINTER(Counters), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
+                                       C.POINTER(C.c_int)]
         L.pto_resolve.argtypes = [_P, C.c_int, C.c_int, _P, C.c_int]
         L.pto_trace_path.argtypes = [C.POINTER(SceneDesc), C.POINTER(Params), C.POINTER(Camera), _P, C.c_int, C.c_float,
                                      C.c_float, C.c_int, _P, C.c_int, _P, C.POINTER(Counters)]
@@ -156,6 +159,19 @@ def render_pass(sd, params, cam, lights, accum=None, nthreads=1, libm=False, blo
     lib().pto_render_pass(C.byref(desc), C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), accum.ctypes.data,
                           C.byref(ctr), nthreads, int(libm), block_begin, block_end)
     return accum, dict(rays=ctr.rays, node_visits=ctr.node_visits, tri_tests=ctr.tri_tests)
+
+
+def render_pass_tiles(sd, params, cam, lights, accum, block_begin, block_stride, nthreads=1, foreign_cap=1024):
+    """One pass over this rank's blocks (block_begin, block_begin + stride, ...).  Returns (accum, foreign [n,8] float32, counters):
+    foreign = the out-of-block samples that landed in another rank's block, in the device's ForeignSpill layout."""
+    desc, keep = make_scene_desc(sd)
+    larr = (Light * len(lights))(*lights)
+    ctr = Counters()
+    foreign = np.zeros((foreign_cap, 8), np.float32)
+    nf = C.c_int(0)
+    lib().pto_render_pass2(C.byref(desc), C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), accum.ctypes.data,
+                           C.byref(ctr), nthreads, 0, block_begin, -1, block_stride, foreign.ctypes.data, foreign_cap, C.byref(nf))
+    return accum, foreign[: nf.value].copy(), dict(rays=ctr.rays, node_visits=ctr.node_visits, tri_tests=ctr.tri_tests)
 
 
 def resolve(accum, libm=False):

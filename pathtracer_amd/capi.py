@@ -97,11 +97,20 @@ SIGNATURES = [
     ("ptgpu_render_pass_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("ptgpu_render_pass", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("ptgpu_resolve_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    ("ptgpu_spill_status", C.c_int, [_P, C.POINTER(C.c_uint64 * 3)]),
+    ("ptgpu_comm_create_id", C.c_int, [_P]),
+    ("ptgpu_comm_init", C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    ("ptgpu_comm_destroy", C.c_int, [_P]),
+    ("ptgpu_gather_tiles_dev", C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    ("ptgpu_tiles_slice_floats", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    ("ptgpu_tiles_pack_dev", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    ("ptgpu_tiles_unpack_dev", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("ptgpu_intersect_triangle1_batch", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
     ("ptgpu_bvh_build_lbvh", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
 ]
 
 NOALLOC_MAX_RAYS = 4194304  # PTGPU_NOALLOC_MAX_RAYS
+COMM_ID_BYTES = 128  # PTGPU_COMM_ID_BYTES
 
 _lib = None
 
@@ -119,6 +128,19 @@ def load_library(path=LIB_PATH):
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def create_comm_id():
+    """Rank 0: a fresh communicator id (bytes) to hand to every rank's Context.comm_init."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(load_library().ptgpu_comm_create_id(C.cast(buf, _P)))
+    return bytes(buf)
+
+
+def tiles_slice_floats(width, height, world):
+    n = C.c_int64()
+    _check(load_library().ptgpu_tiles_slice_floats(width, height, world, C.byref(n)))
+    return n.value
 
 
 def _check(rc):
@@ -186,6 +208,30 @@ class Context:
         c = Counters()
         _check(self.lib.ptgpu_get_counters(self.handle, C.byref(c)))
         return dict(rays=c.rays, node_visits=c.node_visits, tri_tests=c.tri_tests)
+
+    def spill_status(self):
+        """Out-of-block samples of the last Sobol-block pass: dict(spilled, dropped, foreign_pending)."""
+        o = (C.c_uint64 * 3)()
+        _check(self.lib.ptgpu_spill_status(self.handle, C.byref(o)))
+        return dict(spilled=o[0], dropped=o[1], foreign_pending=o[2])
+
+    # ---- image tiles across GPUs (include/ptgpu.h "image tiles") ----
+    def comm_init(self, world, rank, comm_id):
+        """comm_id: the COMM_ID_BYTES bytes rank 0 got from create_comm_id(), the same on every rank (collective)."""
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        _check(self.lib.ptgpu_comm_init(self.handle, world, rank, C.cast(buf, _P)))
+
+    def comm_destroy(self):
+        _check(self.lib.ptgpu_comm_destroy(self.handle))
+
+    def gather_tiles_dev(self, width, height, d_accum):
+        _check(self.lib.ptgpu_gather_tiles_dev(self.handle, width, height, d_accum))
+
+    def tiles_pack_dev(self, width, height, world, rank, d_accum, d_slice):
+        _check(self.lib.ptgpu_tiles_pack_dev(self.handle, width, height, world, rank, d_accum, d_slice))
+
+    def tiles_unpack_dev(self, width, height, world, rank, d_slices, d_accum):
+        _check(self.lib.ptgpu_tiles_unpack_dev(self.handle, width, height, world, rank, d_slices, d_accum))
 
     def resolve_dev(self, d_accum, width, height, d_out):
         _check(self.lib.ptgpu_resolve_dev(self.handle, d_accum, width, height, d_out))

@@ -1,0 +1,72 @@
+// Library-internal state shared by the translation units of libptgpu.so (ptgpu.hip, pt_multigpu.hip).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/ptgpu.h"
+
+// sets the thread-local message behind ptgpu_last_error() and returns `code`
+int ptgpu_vfail(int code, const char* fmt, va_list ap);
+__attribute__((format(printf, 2, 3))) static inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    const int rc = ptgpu_vfail(code, fmt, ap);
+    va_end(ap);
+    return rc;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PTGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// Counter words of a context (unsigned long long each):
+//   [0] rays  [1] node visits  [2] triangle tests                      the public counters (ptgpu_get_counters)
+//   [3] entries in the spill list of the pass in flight    [4] samples dropped because a list was full (last pass)
+//   [5] deferred rays of the raycast launch in flight      [6] entries pending in the foreign-spill list
+//   [8..28] diagnostic stamps (PT_STAMPS builds)
+constexpr int CTR_WORDS = 32;
+constexpr int CTR_SPILL = 3, CTR_DROPPED = 4, CTR_DEFER = 5, CTR_FOREIGN = 6;
+constexpr int SPILL_CAPACITY = 1 << 16;
+// Sobol-block samples whose pixel belongs to a block this process does not render (tile sharding): kept until the tiles are gathered.
+// Expected rate 2^-24 per sample and coordinate, so a handful per pass; 1024 entries per rank travel with every gather (32 KiB).
+constexpr int FOREIGN_CAPACITY = 1024;
+struct ForeignSpill {
+    float r, g, b, w;          // what the sample adds to its pixel, already divided by NumAaRays
+    int32_t pixel, pad0, pad1, pad2;
+};
+static_assert(sizeof(ForeignSpill) == 32, "two float4");
+
+struct ptgpu_comm;  // pt_multigpu.hip
+
+struct ptgpu_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool count = false;
+    unsigned long long* d_counters = nullptr;  // CTR_WORDS words, see above
+    int num_cu = 256;
+    // render workspace (grow-only): per-sample radiance of one batch of blocks, light table, spill lists
+    float4* d_rad = nullptr;
+    size_t rad_capacity = 0;  // samples
+    ptgpu_light* d_lights = nullptr;
+    std::vector<ptgpu_light> h_lights;  // what d_lights holds
+    float4* d_spill = nullptr;
+    ForeignSpill* d_foreign = nullptr;
+    int32_t* d_defer = nullptr;    // indices of the rays a one-ray-per-lane launch gave up for lack of LDS stack
+    size_t defer_capacity = 0;
+    uint2* d_stack_ovf = nullptr;  // global-memory overflow of the per-lane traversal stacks (trees deeper than the LDS stack)
+    size_t stack_ovf_bytes = 0;
+    uint2* d_sobol_pairs = nullptr;  // byte-indexed Sobol table for the integrator (pt_integrator.hip.h sobol32x2), built at init
+    unsigned char* d_stage = nullptr;  // grow-only device staging of the host-pointer entry points (rays in, hit records out, images)
+    size_t stage_bytes = 0;
+    unsigned char* scratch = nullptr;  // THIS device's address of the file-scope scratch array (ptgpu_raycast_batch_dev_noalloc)
+    ptgpu_comm* comm = nullptr;        // tile-gather communicator (ptgpu_comm_init), owned
+};
+
+// pt_multigpu.hip
+int ptgpu_ensure_spill_lists(ptgpu_context* c);
+void ptgpu_comm_release(ptgpu_context* c);

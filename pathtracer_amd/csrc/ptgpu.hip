@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/ptgpu.h"
+#include "pt_context.h"
 #include "pt_traverse.hip.h"
 #include "pt_raycast_step.h"
 #include "pt_integrator.hip.h"
@@ -24,47 +25,12 @@ __device__ const uint32_t g_sobol_matrices[1024 * 52] = {
 
 static_assert(sizeof(ptgpu_flatnode) == 64, "FlatNode must be 64 bytes like the reference's");
 
-// ------------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------------
+// errors: thread-local message behind ptgpu_last_error(), shared with the other translation units through pt_context.h
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
+int ptgpu_vfail(int code, const char* fmt, va_list ap) {
     vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
     return code;
 }
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(PTGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-struct ptgpu_context {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    bool count = false;
-    unsigned long long* d_counters = nullptr;  // rays, node visits, triangle tests, [3] spill entries, [4] spill overflow
-    int num_cu = 256;
-    // render workspace (grow-only): per-sample radiance of one batch of blocks, light table, spill list
-    float4* d_rad = nullptr;
-    size_t rad_capacity = 0;  // samples
-    ptgpu_light* d_lights = nullptr;
-    std::vector<ptgpu_light> h_lights;  // what d_lights holds
-    float4* d_spill = nullptr;
-    int32_t* d_defer = nullptr;    // indices of the rays a one-ray-per-lane launch gave up for lack of LDS stack
-    size_t defer_capacity = 0;
-    uint2* d_stack_ovf = nullptr;  // global-memory overflow of the per-lane traversal stacks (trees deeper than the LDS stack)
-    size_t stack_ovf_bytes = 0;
-    uint2* d_sobol_pairs = nullptr;  // byte-indexed Sobol table for the integrator (pt_integrator.hip.h sobol32x2), built at init
-    unsigned char* d_stage = nullptr;  // grow-only device staging of the host-pointer entry points (rays in, hit records out, images)
-    size_t stage_bytes = 0;
-    unsigned char* scratch = nullptr;  // THIS device's address of the file-scope scratch array (ptgpu_raycast_batch_dev_noalloc)
-};
-constexpr int CTR_WORDS = 32;  // [0..2] public counters, [3..4] spill list, [8..28] diagnostic stamps (PT_STAMPS builds)
-constexpr int SPILL_CAPACITY = 1 << 16;
 
 // What the raycast kernels need beyond their inputs and outputs: counter words, the deferred-ray list of the one-ray-per-lane
 // kernels and the global-memory stack overflow of the persistent ones.  Either the context's grow-only buffers (grow != NULL: sized
@@ -163,7 +129,9 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     if (c->d_counters) hipFree(c->d_counters);
     if (c->d_rad) hipFree(c->d_rad);
     if (c->d_lights) hipFree(c->d_lights);
+    ptgpu_comm_release(c);
     if (c->d_spill) hipFree(c->d_spill);
+    if (c->d_foreign) hipFree(c->d_foreign);
     if (c->d_stack_ovf) hipFree(c->d_stack_ovf);
     if (c->d_defer) hipFree(c->d_defer);
     if (c->d_sobol_pairs) hipFree(c->d_sobol_pairs);
@@ -911,9 +879,9 @@ __global__ __launch_bounds__(256) void k_accum_sobol(ptgpu_params prm, ptd::Pass
                 lp = (gy - by) * 32 + (gx - bx);
                 pending = true;
             } else {
-                const unsigned long long slot = atomicAdd(&counters[3], 1ull);
+                const unsigned long long slot = atomicAdd(&counters[CTR_SPILL], 1ull);
                 if (slot < (unsigned long long)SPILL_CAPACITY) spill[slot] = make_float4(r.x * scale, r.y * scale, r.z * scale, r.w);
-                else atomicAdd(&counters[4], 1ull);
+                else atomicAdd(&counters[CTR_DROPPED], 1ull);
             }
         }
         // add in sample order: among the pending samples of one pixel the lowest thread (= lowest i) goes first
@@ -937,16 +905,36 @@ __global__ __launch_bounds__(256) void k_accum_sobol(ptgpu_params prm, ptd::Pass
     }
 }
 
-__global__ void k_apply_spill(ptgpu_params prm, const float4* __restrict__ spill, float* __restrict__ accum, const unsigned long long* counters) {
-    unsigned long long n = counters[3];
+// Which 32x32 blocks a render call accumulates (block_begin, block_begin + stride, ... < block_end): the pixels of every other block
+// belong to another call -- with tile sharding, to another GPU.
+struct TileOwner {
+    int32_t block_begin, block_end, block_stride, blocks_x;
+};
+__device__ __forceinline__ bool owns_pixel(const TileOwner& o, int gp, int width) {
+    const int idx = ((gp / width) >> 5) * o.blocks_x + ((gp % width) >> 5);
+    return idx >= o.block_begin && idx < o.block_end && (idx - o.block_begin) % o.block_stride == 0;
+}
+
+// Once per pass, after every block sum: out-of-block samples that landed in one of this call's own blocks are added to their pixel; those
+// that landed in a block this call does not render are kept in the context's foreign list for ptgpu_tiles_pack_dev /
+// ptgpu_gather_tiles_dev to deliver to the pixel's owner (adding them here would be overwritten by the owner's tile at the gather).
+__global__ void k_apply_spill(ptgpu_params prm, TileOwner own, const float4* __restrict__ spill, float* __restrict__ accum,
+                              ForeignSpill* __restrict__ foreign, unsigned long long* counters) {
+    unsigned long long n = counters[CTR_SPILL];
     if (n > (unsigned long long)SPILL_CAPACITY) n = SPILL_CAPACITY;
     const float scale = 1.0f / (float)prm.num_aa_rays;
     for (unsigned long long e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * blockDim.x) {
         const float4 s = spill[e];
         const int gp = __float_as_int(s.w);
         if (gp < 0 || gp >= prm.width * prm.height) continue;
-        float* px = accum + (size_t)gp * 4;
-        atomicAdd(px, s.x); atomicAdd(px + 1, s.y); atomicAdd(px + 2, s.z); atomicAdd(px + 3, 1.0f * scale);
+        if (owns_pixel(own, gp, prm.width)) {
+            float* px = accum + (size_t)gp * 4;
+            atomicAdd(px, s.x); atomicAdd(px + 1, s.y); atomicAdd(px + 2, s.z); atomicAdd(px + 3, 1.0f * scale);
+        } else {
+            const unsigned long long slot = atomicAdd(&counters[CTR_FOREIGN], 1ull);
+            if (slot < (unsigned long long)FOREIGN_CAPACITY) foreign[slot] = ForeignSpill{s.x, s.y, s.z, 1.0f * scale, gp, 0, 0, 0};
+            else atomicAdd(&counters[CTR_DROPPED], 1ull);
+        }
     }
 }
 
@@ -1062,7 +1050,10 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
         HIP_TRY(hipMemcpy(c->d_lights, lights, sizeof(ptgpu_light) * num_lights, hipMemcpyHostToDevice));
         c->h_lights.assign(lights, lights + num_lights);
     }
-    if (!c->d_spill) HIP_TRY(hipMalloc(&c->d_spill, sizeof(float4) * SPILL_CAPACITY));
+    rc = ptgpu_ensure_spill_lists(c);
+    if (rc != PTGPU_OK) return rc;
+    // spill list and dropped-sample count are per pass (all batches of this call append to one list, applied after the last block sum)
+    if (prm->sobol_block) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + CTR_SPILL, 2);
     const int count = (block_end - block_begin + block_stride - 1) / block_stride;  // blocks of this call
     const long long spb = 1024LL * prm->num_aa_rays;
     // samples per integrator launch: every launch ends with a tail of waves draining, so few, large launches (the radiance buffer is
@@ -1103,14 +1094,33 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
 #undef PT_LAUNCH
         if (rc != PTGPU_OK) return rc;
         if (prm->sobol_block) {
-            hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + 3, 1);
             hipLaunchKernelGGL(k_accum_sobol, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum, c->d_spill, c->d_counters);
-            hipLaunchKernelGGL(k_apply_spill, dim3(1), dim3(64), 0, c->stream, *prm, c->d_spill, d_accum, c->d_counters);
         } else {
             hipLaunchKernelGGL(k_accum_gauss, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum);
         }
         HIP_TRY(hipGetLastError());
     }
+    if (prm->sobol_block) {
+        const TileOwner own{block_begin, block_end, block_stride, blocks_x};
+        hipLaunchKernelGGL(k_apply_spill, dim3(1), dim3(64), 0, c->stream, *prm, own, c->d_spill, d_accum, c->d_foreign, c->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_spill_status(ptgpu_context* c, uint64_t out[3]) {
+    if (!c || !out) return fail(PTGPU_E_INVALID, "NULL argument");
+    unsigned long long h[4];
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(h, c->d_counters + CTR_SPILL, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[CTR_FOREIGN - CTR_SPILL] < (unsigned long long)FOREIGN_CAPACITY ? h[CTR_FOREIGN - CTR_SPILL] : FOREIGN_CAPACITY;
+    return PTGPU_OK;
+}
+
+int ptgpu_ensure_spill_lists(ptgpu_context* c) {
+    if (!c->d_spill) HIP_TRY(hipMalloc(&c->d_spill, sizeof(float4) * SPILL_CAPACITY));
+    if (!c->d_foreign) HIP_TRY(hipMalloc(&c->d_foreign, sizeof(ForeignSpill) * FOREIGN_CAPACITY));
     return PTGPU_OK;
 }
 
@@ -1131,8 +1141,8 @@ extern "C" int ptgpu_render_pass(ptgpu_scene* s, const ptgpu_params* prm, const 
     HIP_TRY(hipMemcpyAsync(accum, d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     unsigned long long ovf = 0;
-    HIP_TRY(hipMemcpy(&ovf, c->d_counters + 4, sizeof ovf, hipMemcpyDeviceToHost));
-    if (ovf) return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples did not fit the spill list", ovf);
+    HIP_TRY(hipMemcpy(&ovf, c->d_counters + CTR_DROPPED, sizeof ovf, hipMemcpyDeviceToHost));
+    if (ovf) return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples of this pass did not fit the spill lists and were dropped", ovf);
     return PTGPU_OK;
 }
 

@@ -61,8 +61,16 @@ void PathTraceRenderer::launchPass() {
     ptgpu_params p = currentParams();
     PT_GPU(ptgpu_render_pass_dev(m_context.m_rt->deviceScene(), &p, &m_cameraPod, m_lightPods.data(), (int32_t)m_lightPods.size(), m_blockBegin, -1,
                                  m_blockStride, m_accum.ptr()));
+    if (m_gatherTiles) PT_GPU(ptgpu_gather_tiles_dev(GpuDevice::instance().ctx(), p.width, p.height, m_accum.ptr()));
     ++m_passSeed;  // stands in for the reference's process-global seed counter (:689-691): every pass draws new samples
     m_passInFlight = true;
+}
+
+void PathTraceRenderer::setTileRanks(int rank, int world, const void* commId) {
+    if (world <= 1) { m_gatherTiles = false; setBlockSubset(0, 1); return; }
+    PT_GPU(ptgpu_comm_init(GpuDevice::instance().ctx(), world, rank, commId));
+    setBlockSubset(rank, world);
+    m_gatherTiles = true;
 }
 
 void PathTraceRenderer::startPathTracingProcess(const MeshWithColors* scene, std::vector<AreaLight>* lights, RayTracer* rt, Image* dest,
@@ -128,6 +136,9 @@ void PathTraceRenderer::checkFinish() {
     float time = static_cast<float>(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - m_context.start).count()) * 0.001f;
 
     // 1 ray = 1 raycast() call, counted on the device (reference src/RayTracer.cpp:192); fold it into the tracer's counter
+    uint64_t spill[3] = {0, 0, 0};
+    PT_GPU(ptgpu_spill_status(ctx, spill));
+    if (spill[1]) std::fprintf(stderr, "PathTraceRenderer: %llu out-of-block samples of this pass were dropped (spill list full)\n", (unsigned long long)spill[1]);
     ptgpu_counters c{};
     PT_GPU(ptgpu_get_counters(ctx, &c));
     PT_GPU(ptgpu_reset_counters(ctx));

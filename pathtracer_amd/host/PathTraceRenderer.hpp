@@ -77,6 +77,10 @@ public:
     // ---- additions of this build (none changes the reference's behaviour when left alone) ----
     // Multi-GPU tiles: this process renders blocks begin, begin+stride, ... (rank r of N: begin = r, stride = N)
     void setBlockSubset(int begin, int stride) { m_blockBegin = begin; m_blockStride = stride; }
+    // One process per GPU: this process is rank `rank` of `world`; every pass renders its round-robin share of the blocks and ends with
+    // ptgpu_gather_tiles_dev (RCCL all-gather), so updatePicture shows the full image on every rank.  commId: the
+    // PTGPU_COMM_ID_BYTES bytes rank 0 got from ptgpu_comm_create_id, the same on all ranks (collective call).
+    void setTileRanks(int rank, int world, const void* commId);
     void setPrintStats(bool b) { m_printStats = b; }
     void setMaxPasses(int n) { m_maxPasses = n; }  // 0 = run until stop() like the reference
     void waitPass();                               // block until the pass in flight has finished, then checkFinish()
@@ -106,6 +110,7 @@ protected:
 
     bool m_running = false, m_passInFlight = false, m_printStats = true;
     int m_blockBegin = 0, m_blockStride = 1, m_maxPasses = 0;
+    bool m_gatherTiles = false;
     uint32_t m_passSeed = 0;
     GpuBuffer<float> m_accum, m_resolved;
     ptgpu_camera m_cameraPod{};

@@ -4,11 +4,14 @@
 //
 //   ptrender <mesh.ptmesh|mesh.obj> [-builder sah|object_median|spatial_median|lbvh] [-spp N] [-passes N] [-size WxH]
 //            [-bounces N] [-rr] [-aa sobol|gauss] [-filter W] [-normal_maps] [-dof APERTURE FOCAL] [-whitted] [-light_size S] [-emission E]
-//            [-bat_render] [-output_images] [-o out.ppm] [-cache DIR] [-ranks N -rank R]
+//            [-bat_render] [-output_images] [-o out.ppm] [-cache DIR] [-ranks N -rank R [-comm_id FILE]]
 //
 // -bat_render: always build the hierarchy (never the cache) and ignore textures, like the reference's batch mode.
-// -ranks/-rank: render only this rank's round-robin share of the 32x32 blocks (multi-GPU tiles; gather is the caller's).
+// -ranks/-rank: one process per GPU (device = PTGPU_DEVICE or LOCAL_RANK); each renders its round-robin share of the 32x32 blocks.
+// With -comm_id FILE the ranks form an RCCL communicator (rank 0 writes the id to FILE, the others wait for it) and every pass ends
+// with ptgpu_gather_tiles_dev, so each rank holds -- and rank 0 writes -- the full picture; without it only the own tiles are rendered.
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,7 +32,7 @@ int main(int argc, char** argv) {
                              "       [-o out.ppm] [-cache DIR] [-ranks N -rank R]\n");
         return 2;
     }
-    std::string meshPath = argv[1], outPath, cacheDir = ".";
+    std::string meshPath = argv[1], outPath, cacheDir = ".", commIdFile;
     bool sah = true, lbvh = false, batch = false, outputImages = false, rr = false, sobolAA = true, normalMaps = false, dof = false, whitted = false;
     int spp = 4, passes = 1, width = 512, height = 512, bounces = 1, ranks = 1, rank = 0;
     float filterWidth = 1.0f, aperture = 0.0001f, focal = 0.1f, lightSize = 0.25f, emission = 100.0f;
@@ -56,6 +59,7 @@ int main(int argc, char** argv) {
         else if (a == "-cache") cacheDir = next();
         else if (a == "-ranks") ranks = std::atoi(next().c_str());
         else if (a == "-rank") rank = std::atoi(next().c_str());
+        else if (a == "-comm_id") commIdFile = next();
         else std::printf("argument \"%s\" not found!\n", a.c_str());
     }
     try {
@@ -108,6 +112,24 @@ int main(int argc, char** argv) {
         renderer.setDOF(dof); renderer.setAperture(aperture); renderer.setFocalDistance(focal);
         renderer.setWhitted(whitted); renderer.setTermination(0.2f);
         renderer.setBlockSubset(rank, ranks);
+        if (ranks > 1 && !commIdFile.empty()) {
+            unsigned char id[PTGPU_COMM_ID_BYTES];
+            if (rank == 0) {
+                PT_GPU(ptgpu_comm_create_id(id));
+                std::ofstream f(commIdFile + ".tmp", std::ios::binary);
+                f.write((const char*)id, sizeof id);
+                f.close();
+                std::rename((commIdFile + ".tmp").c_str(), commIdFile.c_str());
+            } else {
+                for (int tries = 0; !fileExists(commIdFile); ++tries) {
+                    if (tries > 1200) { std::fprintf(stderr, "no communicator id in %s\n", commIdFile.c_str()); return 1; }
+                    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                }
+                std::ifstream f(commIdFile, std::ios::binary);
+                if (!f.read((char*)id, sizeof id)) { std::fprintf(stderr, "%s: short communicator id\n", commIdFile.c_str()); return 1; }
+            }
+            renderer.setTileRanks(rank, ranks, id);
+        }
         renderer.setMaxPasses(passes);
         Image dest(Vec2i(width, height), ImageFormat::RGBA_Vec4f);
         renderer.startPathTracingProcess(mesh.get(), &lights, &rt, &dest, rr ? -bounces : bounces, camera);
@@ -117,7 +139,7 @@ int main(int argc, char** argv) {
         std::printf("%d pass(es), %.1f Msamples, %.1f Mrays, %.2f Mrays/sec\n", renderer.m_context.m_pass, samples / 1e6,
                     renderer.getTotalRays() / 1e6, renderer.getRaysPerSecond() / 1e6);
         if (outPath.empty() && outputImages) { char fn[64]; std::snprintf(fn, sizeof fn, "pt-%03dppp.ppm", renderer.m_context.m_pass * spp); outPath = fn; }
-        if (!outPath.empty()) {
+        if (!outPath.empty() && (rank == 0 || commIdFile.empty())) {
             if (!exportPPM(outPath, dest, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
             std::printf("Wrote %s\n", outPath.c_str());
         }

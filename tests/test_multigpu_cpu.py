@@ -21,29 +21,47 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, out_dir):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import pyoracle as po
-    from pathtracer_amd import multigpu, scene
+def _soup_scene(po, scene):
     pos = scene.grid_scene(6, 6, seed=2)
     sd = dict(pos=pos, nrm=scene.flat_normals(pos), uv=np.zeros((pos.shape[0], 3, 2), np.float32), mat_id=np.zeros(pos.shape[0], np.int32),
               woop=po.woop_from_positions(pos), materials=[scene.make_material()], textures=[])
     sd["nodes"], sd["list"], _ = po.bvh_build(pos, True)
+    return sd
+
+
+def _empty_scene(capi):
+    return dict(pos=np.zeros((0, 3, 3), np.float32), nrm=np.zeros((0, 3, 3), np.float32), uv=np.zeros((0, 3, 2), np.float32),
+                mat_id=np.zeros(0, np.int32), woop=np.zeros((0, 12), np.float32), materials=[], textures=[],
+                nodes=np.zeros(0, capi.FLATNODE_DTYPE), list=np.zeros(0, np.int32))
+
+
+def _worker(rank, world, port, w, h, spp, empty, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    from pathtracer_amd import capi, multigpu, scene
+    sd = _empty_scene(capi) if empty else _soup_scene(po, scene)
     cam = scene.make_camera(eye=(0, 0, 2.0), forward=(0, 0, -1), fov_deg=60.0, near=0.01, far=6.0, width=w, height=h)
     lights = [scene.make_light(position=(0, 0, 1.5), col0=(1, 0, 0), col1=(0, 1, 0), col2=(0, 0, 1))]
-    prm = scene.make_params(width=w, height=h, bounces=1, num_aa_rays=2, sobol_block=True, pass_seed=4)
-    nb = multigpu.num_blocks(w, h)
-    accum = np.zeros((h, w, 4), np.float32)
-    for b in range(rank, nb, world):  # what ptgpu_render_pass(block_begin=rank, block_stride=world) covers
-        po.render_pass(sd, prm, cam, lights, accum=accum, block_begin=b, block_end=b + 1)
     tg = multigpu.TileGather(w, h, rank, world, torch.device("cpu"))
     assert sum(tg.counts) == w * h
-    full = tg.gather(torch.from_numpy(accum).view(-1)).view(h, w, 4).numpy()
-    np.save(os.path.join(out_dir, "rank%d.npy" % rank), full)
+    accum = np.zeros((h, w, 4), np.float32)
+    n_foreign = 0
+    for seed in (4, 5):  # two passes: the second accumulates onto the gathered image, like PathTraceRenderer's pass loop
+        prm = scene.make_params(width=w, height=h, bounces=1, num_aa_rays=spp, sobol_block=True, pass_seed=seed)
+        # what ptgpu_render_pass_dev(block_begin=rank, block_stride=world) covers, the CPU oracle standing in for the device pass
+        accum, foreign, _ = po.render_pass_tiles(sd, prm, cam, lights, accum, rank, world, nthreads=2)
+        n_foreign += foreign.shape[0]
+        accum = tg.gather(torch.from_numpy(accum).view(-1), foreign).view(h, w, 4).numpy()
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), accum)
+    np.save(os.path.join(out_dir, "foreign%d.npy" % rank), np.array([n_foreign]))
     if rank == 0:
-        ref, _ = po.render_pass(sd, prm, cam, lights)
+        ref = np.zeros((h, w, 4), np.float32)
+        for seed in (4, 5):
+            prm = scene.make_params(width=w, height=h, bounces=1, num_aa_rays=spp, sobol_block=True, pass_seed=seed)
+            ref, f, _ = po.render_pass_tiles(sd, prm, cam, lights, ref, 0, 1, nthreads=4)
+            assert f.shape[0] == 0  # one rank owns every block
         np.save(os.path.join(out_dir, "ref.npy"), ref)
     dist.barrier()
     dist.destroy_process_group()
@@ -56,14 +74,35 @@ def test_tile_partition_covers_image_once():
         seen = np.zeros(w * h, np.int32)
         for r in range(world):
             seen[multigpu.rank_pixel_index(r, world, w, h)] += 1
+            pos, pix = multigpu.rank_slot_index(r, world, w, h)
+            assert np.array_equal(np.sort(pix), np.sort(multigpu.rank_pixel_index(r, world, w, h)))
+            assert pos.size == np.unique(pos).size and (pos.size == 0 or pos.max() < multigpu.blocks_per_rank(w, h, world) * 1024)
         assert (seen == 1).all(), (w, h, world)
 
 
-def test_two_rank_gloo_gather_bit_identical(tmp_path):
-    w, h, world = 100, 70, 2  # clipped edge blocks, 12 blocks dealt 6 / 6
-    mp.spawn(_worker, args=(world, _free_port(), w, h, str(tmp_path)), nprocs=world, join=True)
+def _run(tmp_path, w, h, spp, empty, world=2):
+    mp.spawn(_worker, args=(world, _free_port(), w, h, spp, empty, str(tmp_path)), nprocs=world, join=True)
     ref = np.load(tmp_path / "ref.npy")
-    assert ref[..., :3].max() > 0
     for r in range(world):
         got = np.load(tmp_path / ("rank%d.npy" % r))
-        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "rank %d image differs from the single-process pass" % r
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "rank %d image differs from the single-process passes" % r
+    return ref, sum(int(np.load(tmp_path / ("foreign%d.npy" % r))[0]) for r in range(world))
+
+
+def test_two_rank_gloo_gather_bit_identical(tmp_path):
+    ref, _ = _run(tmp_path, 100, 70, 2, False)  # clipped edge blocks, 12 blocks dealt 6 / 6
+    assert ref[..., :3].max() > 0
+    assert abs(float(ref[..., 3].mean()) - 2.0) < 1e-6
+
+
+def test_two_rank_gather_delivers_out_of_block_samples(tmp_path):
+    """Forced spill: with 32768 samples per pixel every block's Sobol index range contains the index whose dimension-0 value and the
+    one whose dimension-1 value round to exactly 1.0f, so block 0 (rank 0) puts one sample on pixel x = 32 in block 1
+    (rank 1) and one on y = 32 in block 2 (its own).  The scene is empty (every path ends at once), so the weight channel carries the
+    check: every sample adds 1/32768 to some pixel, no sample may be lost when the owner's tile overwrites the other rank's copy."""
+    w, h, spp = 64, 64, 32768
+    ref, n_foreign = _run(tmp_path, w, h, spp, True)
+    assert n_foreign >= 2, "the test no longer forces a cross-rank sample"
+    # 2 passes x 4 blocks x 1024 pixels x 32768 samples of weight 2^-15: sums are exact in float32
+    assert float(ref[..., 3].astype(np.float64).sum()) == 2.0 * w * h
+    assert (ref[..., 3] != 2.0).any(), "no pixel received a neighbour's sample: the spill path was not exercised"
