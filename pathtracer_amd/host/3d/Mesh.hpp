@@ -108,8 +108,13 @@ typedef Mesh<VertexPNTC> MeshWithColors;
 std::unique_ptr<MeshWithColors> importPtMesh(const std::string& path, std::string* err);
 std::unique_ptr<MeshWithColors> importWavefrontMesh(const std::string& path, std::string* err);
 std::unique_ptr<MeshWithColors> importMesh(const std::string& path, std::string* err);  // by extension
-// Binary PPM (P6) -> 8-bit RGBA texture image; the only image file format the headless host reads itself.
+// Image files (ImageIO.cpp, MeshIO.cpp) -> 8-bit RGBA texture image: PNG (the format of the reference's head/*.png maps; own decoder,
+// 8-bit non-interlaced) and binary PPM (P6).  importImage picks by extension.  exportPNG writes the 8-bit RGB picture the reference
+// writes per pass with exportLodePngImage (src/PathTraceRenderer.cpp:900-902).
+std::shared_ptr<Image> importPNG(const std::string& path, std::string* err);
 std::shared_ptr<Image> importPPM(const std::string& path, std::string* err);
+std::shared_ptr<Image> importImage(const std::string& path, std::string* err);
+bool exportPNG(const std::string& path, const Image& img, std::string* err);
 bool exportPPM(const std::string& path, const Image& img, std::string* err);
 
 }  // namespace FW

@@ -1,4 +1,4 @@
-// Headless scene ingestion for the host classes: .ptmesh, Wavefront OBJ/MTL, binary PPM textures.
+// Headless scene ingestion for the host classes: .ptmesh, Wavefront OBJ/MTL, textures as PNG or binary PPM (ImageIO.cpp).
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -18,7 +18,9 @@ bool fail(std::string* err, const std::string& msg) { if (err) *err = msg; retur
 
 struct MtlEntry { MeshBase::Material mat; std::string mapKd, mapBump; };
 
-// textures referenced by a material are attached when a same-named .ppm exists next to the mesh
+// A texture a material names is attached when the file exists next to the mesh -- under the name the .mtl gives (PNG or PPM), else under
+// the same stem with .ppm.  A missing file leaves the slot empty, like an importer that cannot find a map (three of head.mtl's six
+// maps are absent from the reference's own checkout).
 void attachTextures(MeshBase::Material& m, const std::string& dir, const std::string& mapKd, const std::string& mapBump,
                     std::map<std::string, std::shared_ptr<Image>>& cache) {
     auto load = [&](const std::string& name) -> std::shared_ptr<Image> {
@@ -27,7 +29,10 @@ void attachTextures(MeshBase::Material& m, const std::string& dir, const std::st
         auto it = cache.find(stem);
         if (it != cache.end()) return it->second;
         std::string e;
-        return cache[stem] = importPPM(dir + stem + ".ppm", &e);
+        std::shared_ptr<Image> img;
+        if (std::ifstream(dir + name).good()) img = importImage(dir + name, &e);
+        if (!img) img = importPPM(dir + stem + ".ppm", &e);
+        return cache[stem] = img;
     };
     if (auto img = load(mapKd)) m.textures[MeshBase::TextureType_Diffuse] = Texture(img, mapKd);
     if (auto img = load(mapBump)) m.textures[MeshBase::TextureType_Normal] = Texture(img, mapBump);

@@ -151,6 +151,14 @@ void PathTraceRenderer::checkFinish() {
         else std::printf("  Done! time: %5.2f min   ", time / 60.0f);
         std::printf("Total Mrays: %6.1f (%5.2f Mrays/sec)\n", m_TotalRays / 1000000.0f, m_raysPerSecond / 1000000.0f);
     }
+    if (!m_outputDir.empty() && m_context.m_destImage) {
+        // after the completion of each full round through the image (reference :900-902)
+        updatePicture(m_context.m_destImage);
+        char fn[64];
+        std::snprintf(fn, sizeof fn, "pt-%03dppp.png", m_context.m_pass);
+        std::string err;
+        if (!exportPNG(m_outputDir + "/" + fn, *m_context.m_destImage, &err)) std::fprintf(stderr, "PathTraceRenderer: %s\n", err.c_str());
+    }
     if (!m_context.m_bForceExit && (m_maxPasses <= 0 || m_context.m_pass < m_maxPasses)) {
         launchPass();
         if (m_printStats) std::printf("Pass %d\n", m_context.m_pass);

@@ -82,6 +82,9 @@ public:
     // PTGPU_COMM_ID_BYTES bytes rank 0 got from ptgpu_comm_create_id, the same on all ranks (collective call).
     void setTileRanks(int rank, int world, const void* commId);
     void setPrintStats(bool b) { m_printStats = b; }
+    // The reference writes "pt-%03dppp.png" after every pass (src/PathTraceRenderer.cpp:900-902); here that is opt-in (a library should
+    // not litter the working directory): directory to write into, empty = off.
+    void setOutputImages(const std::string& dir) { m_outputDir = dir; }
     void setMaxPasses(int n) { m_maxPasses = n; }  // 0 = run until stop() like the reference
     void waitPass();                               // block until the pass in flight has finished, then checkFinish()
     unsigned long long getTotalRays() const { return m_TotalRays; }
@@ -111,6 +114,7 @@ protected:
     bool m_running = false, m_passInFlight = false, m_printStats = true;
     int m_blockBegin = 0, m_blockStride = 1, m_maxPasses = 0;
     bool m_gatherTiles = false;
+    std::string m_outputDir;
     uint32_t m_passSeed = 0;
     GpuBuffer<float> m_accum, m_resolved;
     ptgpu_camera m_cameraPod{};

@@ -1,5 +1,6 @@
 // C shim over the C++ host classes so that pytest (ctypes) and bench.py can drive them.  Not part of the drop-in
 // boundary (that is include/ptgpu.h); this only exposes FW::BVH / RayTracer / AreaLight / CameraControls to Python.
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -112,6 +113,32 @@ uint32_t pth_random_u32(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint
 }
 void pth_md5(const void* data, uint64_t len, char out33[33]) { std::memcpy(out33, md5Hex(data, len).c_str(), 33); }
 
+// ---- image files (ImageIO.cpp): decoded 8-bit RGBA texture, picture out ----
+int pth_image_load(const char* path, void** out_handle, int32_t wh[2]) {
+    return guarded([&] {
+        std::string err;
+        std::shared_ptr<Image> img = importImage(path, &err);
+        if (!img) throw std::runtime_error(err);
+        wh[0] = img->getSize().x; wh[1] = img->getSize().y;
+        *out_handle = new std::shared_ptr<Image>(img);
+    });
+}
+void pth_image_copy(void* h, uint8_t* out_rgba) {
+    const Image& img = **static_cast<std::shared_ptr<Image>*>(h);
+    std::memcpy(out_rgba, img.getPtr(), (size_t)img.getSize().x * img.getSize().y * 4);
+}
+void pth_image_free(void* h) { delete static_cast<std::shared_ptr<Image>*>(h); }
+// rgba: [h][w][4] floats in [0,1] (a resolved picture); written as 8-bit RGB PNG (.png) or PPM (.ppm)
+int pth_image_save(const char* path, const float* rgba, int32_t w, int32_t h) {
+    return guarded([&] {
+        Image img(Vec2i(w, h), ImageFormat::RGBA_Vec4f);
+        std::memcpy(img.getMutablePtr(), rgba, (size_t)w * h * 16);
+        std::string err, p = path;
+        const bool ok = (p.size() > 4 && p.substr(p.size() - 4) == ".ppm") ? exportPPM(p, img, &err) : exportPNG(p, img, &err);
+        if (!ok) throw std::runtime_error(err);
+    });
+}
+
 // ---- RayTracer over a mesh file ----
 int pth_rt_open(const char* mesh_path, int sah, void** out) {
     return guarded([&] {
@@ -134,6 +161,38 @@ int pth_rt_get_bvh(void* h, int32_t* out_list, void* out_nodes) {
     TracerBox* b = static_cast<TracerBox*>(h);
     std::memcpy(out_list, b->rt.bvh.list.data(), b->rt.bvh.list.size() * 4);
     std::memcpy(out_nodes, b->rt.bvh.nodes.data(), b->rt.bvh.nodes.size() * sizeof(FlatNode));
+    return 0;
+}
+// the triangle array App::constructTracer builds (reference src/App.cpp:826-838): pos/nrm [n][3][3], uv [n][3][2], submesh (material) index [n]
+int pth_rt_get_triangles(void* h, float* pos, float* nrm, float* uv, int32_t* mat_id) {
+    TracerBox* b = static_cast<TracerBox*>(h);
+    for (size_t i = 0; i < b->tris.size(); ++i) {
+        for (int k = 0; k < 3; ++k) {
+            const VertexPNTC& v = b->tris[i].m_vertices[k];
+            std::memcpy(pos + i * 9 + k * 3, &v.p, 12);
+            std::memcpy(nrm + i * 9 + k * 3, &v.n, 12);
+            std::memcpy(uv + i * 6 + k * 2, &v.t, 8);
+        }
+        int m = -1;
+        for (int sub = 0; sub < b->mesh->numSubmeshes(); ++sub)
+            if (b->tris[i].m_material == &b->mesh->material(sub)) m = sub;
+        mat_id[i] = m;
+    }
+    return 0;
+}
+int pth_rt_num_materials(void* h) { return static_cast<TracerBox*>(h)->mesh->numSubmeshes(); }
+// material i: out_f = diffuse rgba, specular rgb, glossiness; out_tex = {width, height} of the diffuse and of the normal map (0 0 = none)
+int pth_rt_material(void* h, int i, char name64[64], float out_f[8], int32_t out_tex[4]) {
+    TracerBox* b = static_cast<TracerBox*>(h);
+    if (i < 0 || i >= b->mesh->numSubmeshes()) return -1;
+    const MeshBase::Material& m = b->mesh->material(i);
+    std::snprintf(name64, 64, "%s", m.name.c_str());
+    std::memcpy(out_f, &m.diffuse, 16); std::memcpy(out_f + 4, &m.specular, 12); out_f[7] = m.glossiness;
+    const Texture* t[2] = {&m.textures[MeshBase::TextureType_Diffuse], &m.textures[MeshBase::TextureType_Normal]};
+    for (int k = 0; k < 2; ++k) {
+        out_tex[2 * k] = t[k]->exists() ? t[k]->getImage()->getSize().x : 0;
+        out_tex[2 * k + 1] = t[k]->exists() ? t[k]->getImage()->getSize().y : 0;
+    }
     return 0;
 }
 int pth_rt_save_hierarchy(void* h, const char* path) { return guarded([&] { auto* b = static_cast<TracerBox*>(h); b->rt.saveHierarchy(path, b->tris); }); }

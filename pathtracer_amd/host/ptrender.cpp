@@ -4,7 +4,7 @@
 //
 //   ptrender <mesh.ptmesh|mesh.obj> [-builder sah|object_median|spatial_median|lbvh] [-spp N] [-passes N] [-size WxH]
 //            [-bounces N] [-rr] [-aa sobol|gauss] [-filter W] [-normal_maps] [-dof APERTURE FOCAL] [-whitted] [-light_size S] [-emission E]
-//            [-bat_render] [-output_images] [-o out.ppm] [-cache DIR] [-ranks N -rank R [-comm_id FILE]]
+//            [-bat_render] [-output_images] [-o out.png|out.ppm] [-cache DIR] [-ranks N -rank R [-comm_id FILE]]
 //
 // -bat_render: always build the hierarchy (never the cache) and ignore textures, like the reference's batch mode.
 // -ranks/-rank: one process per GPU (device = PTGPU_DEVICE or LOCAL_RANK); each renders its round-robin share of the 32x32 blocks.
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: ptrender <mesh> [-builder sah|object_median|spatial_median|lbvh] [-spp N] [-passes N] [-size WxH] [-bounces N] [-rr]\n"
                              "       [-aa sobol|gauss] [-filter W] [-normal_maps] [-dof APERTURE FOCAL] [-light_size S] [-bat_render] [-output_images]\n"
-                             "       [-o out.ppm] [-cache DIR] [-ranks N -rank R]\n");
+                             "       [-o out.png|out.ppm] [-cache DIR] [-ranks N -rank R]\n");
         return 2;
     }
     std::string meshPath = argv[1], outPath, cacheDir = ".", commIdFile;
@@ -131,6 +131,7 @@ int main(int argc, char** argv) {
             renderer.setTileRanks(rank, ranks, id);
         }
         renderer.setMaxPasses(passes);
+        if (outputImages) renderer.setOutputImages(".");
         Image dest(Vec2i(width, height), ImageFormat::RGBA_Vec4f);
         renderer.startPathTracingProcess(mesh.get(), &lights, &rt, &dest, rr ? -bounces : bounces, camera);
         while (renderer.isRunning()) renderer.waitPass();
@@ -138,9 +139,9 @@ int main(int argc, char** argv) {
         double samples = (double)width * height * spp * passes / ranks;
         std::printf("%d pass(es), %.1f Msamples, %.1f Mrays, %.2f Mrays/sec\n", renderer.m_context.m_pass, samples / 1e6,
                     renderer.getTotalRays() / 1e6, renderer.getRaysPerSecond() / 1e6);
-        if (outPath.empty() && outputImages) { char fn[64]; std::snprintf(fn, sizeof fn, "pt-%03dppp.ppm", renderer.m_context.m_pass * spp); outPath = fn; }
         if (!outPath.empty() && (rank == 0 || commIdFile.empty())) {
-            if (!exportPPM(outPath, dest, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            const bool ppm = outPath.size() > 4 && outPath.substr(outPath.size() - 4) == ".ppm";
+            if (!(ppm ? exportPPM(outPath, dest, &err) : exportPNG(outPath, dest, &err))) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
             std::printf("Wrote %s\n", outPath.c_str());
         }
     } catch (const std::exception& e) {

@@ -39,10 +39,17 @@ def lib():
         L.pth_random_u32.restype = C.c_uint32
         L.pth_random_u32.argtypes = [C.c_uint32] * 5
         L.pth_md5.argtypes = [_P, C.c_uint64, _P]
+        L.pth_image_load.argtypes = [C.c_char_p, C.POINTER(_P), _P]
+        L.pth_image_copy.argtypes = [_P, _P]
+        L.pth_image_free.argtypes = [_P]
+        L.pth_image_save.argtypes = [C.c_char_p, _P, C.c_int32, C.c_int32]
         L.pth_rt_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(_P)]
         L.pth_rt_close.argtypes = [_P]
         L.pth_rt_counts.argtypes = [_P, _P]
         L.pth_rt_get_bvh.argtypes = [_P, _P, _P]
+        L.pth_rt_get_triangles.argtypes = [_P, _P, _P, _P, _P]
+        L.pth_rt_num_materials.argtypes = [_P]
+        L.pth_rt_material.argtypes = [_P, C.c_int, _P, _P, _P]
         L.pth_rt_save_hierarchy.argtypes = [_P, C.c_char_p]
         L.pth_rt_load_hierarchy.argtypes = [_P, C.c_char_p]
         L.pth_rt_construct_on_device.argtypes = [_P, C.c_int]
@@ -118,6 +125,24 @@ def md5_hex(data):
     return out.value.decode()
 
 
+def load_image(path):
+    """FW::importImage (host/ImageIO.cpp: the build's own PNG decoder, or binary PPM) -> uint8 array [h,w,4]."""
+    h, wh = _P(), np.zeros(2, np.int32)
+    _check(lib().pth_image_load(os.fspath(path).encode(), C.byref(h), wh.ctypes.data))
+    try:
+        out = np.empty((int(wh[1]), int(wh[0]), 4), np.uint8)
+        lib().pth_image_copy(h, out.ctypes.data)
+    finally:
+        lib().pth_image_free(h)
+    return out
+
+
+def save_image(path, rgba):
+    """FW::exportPNG / exportPPM of a resolved float picture [h,w,4] in [0,1] (8-bit RGB out)."""
+    a = _f32(rgba)
+    _check(lib().pth_image_save(os.fspath(path).encode(), a.ctypes.data, a.shape[1], a.shape[0]))
+
+
 class HostRayTracer:
     """FW::RayTracer over a mesh file: App::constructTracer's triangle array + constructHierarchy."""
 
@@ -140,6 +165,23 @@ class HostRayTracer:
         nodes, lst = np.zeros(int(c[1]), FLATNODE_DTYPE), np.zeros(int(c[2]), np.int32)
         lib().pth_rt_get_bvh(self.h, lst.ctypes.data, nodes.ctypes.data)
         return nodes, lst
+
+    def triangles(self):
+        """App::constructTracer's triangle array: dict(pos [n,3,3], nrm [n,3,3], uv [n,3,2], mat_id [n])."""
+        n = self.num_tris
+        out = dict(pos=np.empty((n, 3, 3), np.float32), nrm=np.empty((n, 3, 3), np.float32), uv=np.empty((n, 3, 2), np.float32),
+                   mat_id=np.empty(n, np.int32))
+        lib().pth_rt_get_triangles(self.h, out["pos"].ctypes.data, out["nrm"].ctypes.data, out["uv"].ctypes.data, out["mat_id"].ctypes.data)
+        return out
+
+    def materials(self):
+        out = []
+        for i in range(lib().pth_rt_num_materials(self.h)):
+            name, f, t = C.create_string_buffer(64), np.zeros(8, np.float32), np.zeros(4, np.int32)
+            lib().pth_rt_material(self.h, i, name, f.ctypes.data, t.ctypes.data)
+            out.append(dict(name=name.value.decode(), diffuse=tuple(f[:4]), specular=tuple(f[4:7]), glossiness=float(f[7]),
+                            diffuse_map=tuple(int(x) for x in t[:2]), normal_map=tuple(int(x) for x in t[2:])))
+        return out
 
     def save_hierarchy(self, path):
         _check(lib().pth_rt_save_hierarchy(self.h, path.encode()))

@@ -128,6 +128,43 @@ def value_noise_texture(seed, size=256, octaves=4, normal_map=False):
     return out
 
 
+HEAD_TEXTURE_DIR = ASSETS  # next to head.ptmesh, where the host importer looks for the maps a material names
+
+
+def head_textures(mesh, size=1600):
+    """The six maps head.mtl names, as BASELINE configs[2] / SURVEY.md 8d C3 specify them: the three files the reference checkout
+    holds (assets/: concrete1.png = floor map_Kd, concrete1_normal.png = floor map_bump, concrete2_normal.png = wall map_bump,
+    copied by tools/import_head_textures.py, decoded by the host library's own PNG reader) and seeded value-noise stand-ins of the same
+    size for the three missing ones (lambertian.png, normal.png, concrete2.png).  Returns (textures, name -> index, labels)."""
+    from . import hostapi
+    textures, index, labels = [], {}, {}
+    for m in mesh["materials"]:
+        for name, is_normal in ((m["map_kd"], False), (m["map_bump"], True)):
+            if name and name not in index:
+                index[name] = len(textures)
+                path = os.path.join(HEAD_TEXTURE_DIR, name)
+                if os.path.exists(path):
+                    textures.append(hostapi.load_image(path))
+                    labels[name] = "reference file"
+                else:
+                    textures.append(value_noise_texture(17 + 2 * len(textures) + (0 if is_normal else 1), size, normal_map=is_normal))
+                    labels[name] = "procedural stand-in"
+    return textures, index, labels
+
+
+def head_reference_textures(mesh):
+    """Only the maps that exist as files next to head.ptmesh -- what the host importer attaches when it loads the mesh
+    (host/MeshIO.cpp attachTextures): floor map_Kd + map_bump, wall map_bump.  Returns (textures, name -> index)."""
+    from . import hostapi
+    textures, index = [], {}
+    for m in mesh["materials"]:
+        for name in (m["map_kd"], m["map_bump"]):
+            if name and name not in index and os.path.exists(os.path.join(HEAD_TEXTURE_DIR, name)):
+                index[name] = len(textures)
+                textures.append(hostapi.load_image(os.path.join(HEAD_TEXTURE_DIR, name)))
+    return textures, index
+
+
 def head_standin_textures(mesh, size=1600):
     """Procedural stand-ins (seeded value noise, size x size RGBA8) for the six maps head.mtl names.  Three of them are
     missing from the reference checkout (lambertian.png, normal.png, concrete2.png) and none may be read on the

@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from pathtracer_amd import capi, hostapi, scene
 
@@ -128,3 +129,89 @@ def test_camera_pod_unprojects_pixel_centres(oracle):
     ow, dw = oracle.gen_primary(wide, 130, 65)
     # fitToView keeps the vertical field of view and widens the horizontal one
     assert np.allclose(dw[32 * 130 + 65 + 32] / np.linalg.norm(dw[32 * 130 + 65 + 32]), d[32 * 65 + 64] / np.linalg.norm(d[32 * 65 + 64]), atol=2e-2)
+
+
+def test_png_decoder_matches_pil_on_reference_maps(tmp_path):
+    """host/ImageIO.cpp (own inflate + PNG unfilter) against PIL on the three maps the reference checkout holds for head.obj
+    (assets/, byte copies made by tools/import_head_textures.py), and the stored-deflate writer round trip."""
+    PIL = pytest.importorskip("PIL.Image")
+    from pathtracer_amd import hostapi, scene
+    for name in ("concrete1.png", "concrete1_normal.png", "concrete2_normal.png"):
+        path = os.path.join(scene.HEAD_TEXTURE_DIR, name)
+        got = hostapi.load_image(path)
+        want = np.asarray(PIL.open(path).convert("RGBA"))
+        assert got.shape == want.shape == (1600, 1600, 4)
+        assert np.array_equal(got, want), name
+    # writer: 8-bit RGB, readable by PIL and by the own reader; palette / grey+alpha / RGBA inputs through PIL-made files
+    rng = np.random.RandomState(3)
+    pic = rng.rand(37, 53, 4).astype(np.float32)
+    out = tmp_path / "pic.png"
+    hostapi.save_image(out, pic)
+    q = (np.clip(pic[..., :3], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    assert np.array_equal(np.asarray(PIL.open(out).convert("RGB")), q)
+    assert np.array_equal(hostapi.load_image(out)[..., :3], q)
+    for mode in ("P", "LA", "RGBA", "L"):
+        f = tmp_path / ("m_%s.png" % mode)
+        src = PIL.fromarray((rng.rand(19, 23, 4) * 255).astype(np.uint8), "RGBA").convert(mode)
+        src.save(f)
+        assert np.array_equal(hostapi.load_image(f), np.asarray(src.convert("RGBA"))), mode
+    with pytest.raises(hostapi.HostError):
+        bad = bytearray(open(out, "rb").read())
+        bad[60] ^= 0xFF
+        (tmp_path / "bad.png").write_bytes(bytes(bad))
+        hostapi.load_image(tmp_path / "bad.png")
+
+
+def test_head_textures_mix_reference_files_and_standins():
+    from pathtracer_amd import scene
+    mesh = scene.load_ptmesh()
+    tex, index, labels = scene.head_textures(mesh, size=64)
+    assert len(tex) == 6 and sorted(index) == sorted(["lambertian.png", "normal.png", "concrete2.png", "concrete2_normal.png",
+                                                      "concrete1.png", "concrete1_normal.png"])
+    assert sorted(n for n, l in labels.items() if l == "reference file") == ["concrete1.png", "concrete1_normal.png", "concrete2_normal.png"]
+    assert tex[index["concrete1.png"]].shape == (1600, 1600, 4) and tex[index["lambertian.png"]].shape == (64, 64, 4)
+
+
+def test_import_wavefront_mesh_small():
+    """importWavefrontMesh (host/MeshIO.cpp; stands in for FW's importer behind App::loadMesh, reference src/App.cpp:754-794) and
+    App::constructTracer's triangle array (:826-838) on tests/data/mini.obj: polygon fans, negative indices, v//vn and v/vt corners,
+    faces without normals, one submesh per material in order of first use, map_Kd attached as PNG, a missing map_bump left empty."""
+    from pathtracer_amd import hostapi
+    rt = hostapi.HostRayTracer(os.path.join(os.path.dirname(__file__), "data", "mini.obj"), sah=True)
+    try:
+        t, mats = rt.triangles(), rt.materials()
+        assert [m["name"] for m in mats] == ["checker", "plain"]
+        assert np.allclose(mats[0]["diffuse"][:3], (0.5, 0.6, 0.7)) and np.allclose(mats[0]["specular"], 0.15) and mats[0]["glossiness"] == 50.0
+        assert mats[0]["diffuse_map"] == (12, 8) and mats[0]["normal_map"] == (0, 0) and mats[1]["diffuse_map"] == (0, 0)
+        # submesh 0 (checker): the quad as a fan (2 triangles) + the last face; submesh 1 (plain): two triangles
+        assert t["mat_id"].tolist() == [0, 0, 0, 1, 1]
+        V = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1]], np.float32)
+        assert np.array_equal(t["pos"][0], V[[0, 1, 2]]) and np.array_equal(t["pos"][1], V[[0, 2, 3]])
+        assert np.array_equal(t["pos"][2], V[[4, 5, 2]])
+        assert np.array_equal(t["pos"][3], V[[0, 1, 5]]) and np.array_equal(t["pos"][4], V[[4, 5, 0]])  # -2 -1 1 = vertices 5 6 1
+        assert np.array_equal(t["uv"][0], np.array([[0, 0], [2, 0], [2, 3]], np.float32))
+        assert np.array_equal(t["nrm"][0], np.tile(np.array([0, 0, 1], np.float32), (3, 1)))
+        # faces without vn get the geometric normal: triangle 4 lies in the y = 0 plane
+        assert np.allclose(np.abs(t["nrm"][4]), np.tile(np.array([0, 1, 0], np.float32), (3, 1)))
+        assert rt.num_nodes >= 1 and rt.list_size == 5
+    finally:
+        rt.close()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/head/head.obj"), reason="build container only: reads the reference's head.obj")
+def test_import_wavefront_head_obj_equals_ptmesh():
+    """The reference's head/head.obj through importWavefrontMesh gives the per-triangle arrays assets/head.ptmesh holds
+    (tools/convert_head_obj.py wrote that file with an independent Python reader), so GPU-box tests that load the .ptmesh render the
+    mesh a maintainer gets from the .obj."""
+    from pathtracer_amd import hostapi, scene
+    rt = hostapi.HostRayTracer("/root/reference/head/head.obj", sah=True)
+    try:
+        t, mesh = rt.triangles(), scene.load_ptmesh()
+        assert rt.num_tris == 17692 and [m["name"] for m in rt.materials()] == [m["name"] for m in mesh["materials"]]
+        for k in ("pos", "nrm", "uv"):
+            assert np.array_equal(t[k].view(np.uint32), mesh[k].view(np.uint32)), k
+        assert np.array_equal(t["mat_id"], mesh["mat_id"])
+        maps = {m["name"]: (m["diffuse_map"], m["normal_map"]) for m in rt.materials()}
+        assert maps["floor"] == ((1600, 1600), (1600, 1600)) and maps["wall"] == ((0, 0), (1600, 1600)) and maps["head"] == ((0, 0), (0, 0))
+    finally:
+        rt.close()

@@ -68,8 +68,13 @@ def test_host_path_trace_renderer_matches_oracle(host_rt, head, oracle):
     """FW::PathTraceRenderer (start -> checkFinish per pass -> updatePicture) over the device pass: two passes accumulate exactly
     what two oracle passes with pass seeds 0 and 1 accumulate; the display image is the oracle's resolve; rays are counted."""
     w, h = 80, 48
-    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=True)
+    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=True, normal_mapped=True)
     lights = [scene.make_light()]
+    # the host importer attached the maps that exist next to head.ptmesh (floor Kd + normal, wall normal): same scene for the oracle
+    tex, index = scene.head_reference_textures(head["mesh"])
+    assert len(tex) == 3
+    sd = dict(head["sd"])
+    sd["materials"], sd["textures"] = scene.mesh_materials(head["mesh"], textured=True, texture_index=index), tex
     host_rt.reset_ray_counter()  # like the reference, a pass adds whatever the tracer counted since its last reset
     accum, resolved, rays, passes = host_rt.path_trace(prm, lights, passes=2)
     assert passes == 2
@@ -77,7 +82,7 @@ def test_host_path_trace_renderer_matches_oracle(host_rt, head, oracle):
     c, total = None, 0
     for seed in (0, 1):
         prm.pass_seed = seed
-        c, ctr = oracle.render_pass(head["sd"], prm, cam, lights, accum=c, nthreads=8)
+        c, ctr = oracle.render_pass(sd, prm, cam, lights, accum=c, nthreads=8)
         total += ctr["rays"]
     assert np.array_equal(accum.view(np.uint32), c.view(np.uint32))
     assert np.array_equal(resolved.view(np.uint32), oracle.resolve(c, libm=False).view(np.uint32))
@@ -111,3 +116,50 @@ def test_host_device_built_hierarchy(head, oracle, tmp_path):
         assert np.array_equal(l2, lst)
     finally:
         rt.close()
+
+
+def _run_ptrender(tmp_path, *args):
+    import subprocess
+    exe = os.path.join(os.path.dirname(hostapi.LIB_PATH), "ptrender")
+    assert os.path.exists(exe), "pathtracer_amd/ptrender is not built (run __graft_entry__.build())"
+    r = subprocess.run([exe, scene.HEAD_MESH] + [str(a) for a in args], cwd=str(tmp_path), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_ptrender_cli_picture_matches_oracle(tmp_path, head, oracle):
+    """ptrender = the headless App (reference src/App.cpp:146-239 process_args, :821-908 constructTracer, :457-489 path-trace mode):
+    -builder / -spp / -bat_render as the reference spells them; its PNG must be the oracle's resolved picture, quantised to 8 bits,
+    and -output_images must leave the reference's per-pass "pt-%03dppp.png" (src/PathTraceRenderer.cpp:900-902)."""
+    w, h = 96, 64
+    out = _run_ptrender(tmp_path, "-builder", "sah", "-spp", 2, "-size", "%dx%d" % (w, h), "-rr", "-bat_render", "-passes", 2, "-output_images",
+                        "-o", "out.png")
+    assert "Triangles: 17692  nodes: 15619" in out and "2 pass(es)" in out
+    cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]
+    acc = None
+    pictures = []
+    for seed in (0, 1):
+        prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=True, attenuation=1.0, filter_width=1.0,
+                                focal_distance=0.5, aperture=0.0, pass_seed=seed)
+        acc, _ = oracle.render_pass(head["sd"], prm, cam, lights, accum=acc, nthreads=8)
+        pic = oracle.resolve(acc)
+        pictures.append((np.clip(pic[..., :3], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8))
+    assert np.array_equal(hostapi.load_image(tmp_path / "out.png")[..., :3], pictures[1])
+    assert np.array_equal(hostapi.load_image(tmp_path / "pt-001ppp.png")[..., :3], pictures[0])
+    assert np.array_equal(hostapi.load_image(tmp_path / "pt-002ppp.png")[..., :3], pictures[1])
+
+
+def test_ptrender_lbvh_builder_and_cache(tmp_path):
+    """-builder lbvh (device-built tree) renders the same picture as the SAH tree up to grazing-ray ties, and without -bat_render the
+    MD5-named hierarchy cache file is written and then loaded (reference src/App.cpp:841-892)."""
+    w, h = 64, 48
+    args = ["-spp", 4, "-size", "%dx%d" % (w, h), "-bounces", 1, "-cache", "."]
+    out1 = _run_ptrender(tmp_path, "-builder", "sah", *args, "-o", "sah.png")
+    assert "Saved hierarchy to" in out1
+    out2 = _run_ptrender(tmp_path, "-builder", "sah", *args, "-o", "sah2.png")
+    assert "Loaded hierarchy from" in out2
+    a, b = hostapi.load_image(tmp_path / "sah.png"), hostapi.load_image(tmp_path / "sah2.png")
+    assert np.array_equal(a, b) and a[..., :3].max() > 30
+    _run_ptrender(tmp_path, "-builder", "lbvh", *args, "-o", "lbvh.png")
+    c = hostapi.load_image(tmp_path / "lbvh.png")
+    assert np.abs(a[..., :3].astype(np.int32) - c[..., :3].astype(np.int32)).mean() < 1.0
