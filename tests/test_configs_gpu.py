@@ -1,0 +1,173 @@
+"""BASELINE.json configs[2] and configs[4] exercised AS WRITTEN on the GPU (the smaller parity tests cover the same features on a
+triangle soup; here they meet at the sizes the benchmark is quoted on).
+
+configs[2]: head.obj full path trace 1920x1080, 256 spp, tangent-space normal maps, bilinear textures, Gaussian AA, Russian roulette --
+the six maps head.mtl names at 1600x1600 (scene.head_textures: the three files the reference checkout holds for floor and wall, seeded
+stand-ins for the three it lacks).  Selected 32x32 blocks (face, wall, floor, clipped bottom row, right edge) are
+bit-exact against oracle.render_pass on the same blocks (reference src/PathTraceRenderer.cpp:743-787 pathTraceBlock Gaussian mode,
+:75-181 getTextureParameters); the full frame is checked through size-independent properties.
+configs[4]: 10 M-triangle procedural cloud with depth of field (Shirley-Chiu aperture): sampled primary and incoherent any-hit rays and
+a 64x64 DoF pass bit-exact against the oracle on the same host-built SAH tree.
+Image criterion of north_star (converged image vs the reference's libm arithmetic): per-pixel RMSE < 2e-3 and relative mean luminance
+< 1e-3 on the textured Gaussian configuration at 64 spp."""
+import numpy as np
+import pytest
+
+from pathtracer_amd import capi, hostapi, scene
+
+pytestmark = pytest.mark.gpu
+
+W, H, SPP = 1920, 1080, 256
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _differing_words(g, c):
+    """Words that differ, a NaN matching any NaN: the reference's tangent frame (src/PathTraceRenderer.cpp:158-163) divides by the uv
+    determinant unguarded, head.obj has 16 triangles with degenerate uvs, and a hit on one gives a NaN shading normal and a NaN pixel
+    -- in the reference, in the oracle and on the device alike; only the NaN's sign bit differs between x86 and gfx950."""
+    return (_bits(g) != _bits(c)) & ~(np.isnan(g) & np.isnan(c))
+
+
+@pytest.fixture(scope="module")
+def head_textured(head):
+    tex, index, labels = scene.head_textures(head["mesh"])
+    assert sorted(l for l in labels.values()).count("reference file") == 3 and all(t.shape == (1600, 1600, 4) for t in tex)
+    sd = dict(head["sd"])
+    sd["materials"], sd["textures"] = scene.mesh_materials(head["mesh"], textured=True, texture_index=index), tex
+    return sd
+
+
+@pytest.fixture(scope="module")
+def head_textured_gpu(gpu_ctx, head_textured):
+    s = capi.Scene(gpu_ctx, head_textured)
+    yield s
+    s.close()
+
+
+def _c2_params(seed, w=W, h=H, spp=SPP):
+    return scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=spp, sobol_block=False, bilinear=True, normal_mapped=True,
+                             filter_width=1.5, termination_prob=0.2, pass_seed=seed)
+
+
+def test_config2_selected_blocks_exact(head_textured_gpu, head_textured, oracle):
+    """1920x1080, 256 spp: 12 blocks x 1024 pixels x 256 samples = 3.1 M samples, every accumulated pixel word equal to the oracle's."""
+    cam, lights = scene.make_camera(width=W, height=H), [scene.make_light()]
+    bx, by = (W + 31) // 32, (H + 31) // 32  # 60 x 34, bottom row 24 pixels high
+    blocks = [(30, 12), (27, 16), (33, 20), (29, 25),       # face / neck / shoulders (image centre)
+              (2, 3), (57, 5), (10, 14),                     # wall
+              (12, 30), (40, 31),                            # floor
+              (0, by - 1), (35, by - 1), (bx - 1, by - 1)]   # clipped bottom row, bottom-right corner
+    prm = _c2_params(7)
+    g = np.zeros((H, W, 4), np.float32)
+    c = np.zeros((H, W, 4), np.float32)
+    for (x, y) in blocks:
+        b = y * bx + x
+        g = head_textured_gpu.render_pass(prm, cam, lights, accum=g, block_begin=b, block_end=b + 1)
+    import concurrent.futures as cf
+    def one(xy):
+        b = xy[1] * bx + xy[0]
+        part, ctr = oracle.render_pass(head_textured, prm, cam, lights, nthreads=1, block_begin=b, block_end=b + 1)
+        return part, ctr
+    with cf.ThreadPoolExecutor(8) as ex:  # the oracle call releases the GIL (ctypes): one block per thread
+        for part, ctr in ex.map(one, blocks):
+            c += part  # blocks are disjoint: adding zeros elsewhere
+    touched = c[..., 3] != 0
+    assert touched.sum() == sum(min(32, W - 32 * x) * min(32, H - 32 * y) for x, y in blocks)
+    assert np.nanmax(c[..., :3]) > 0.05 and (c[..., 3][touched] == 1.0).all() and np.isnan(c).sum() < 50
+    diff = _differing_words(g, c)
+    assert not diff.any(), "%d of %d accumulation words differ (max abs %.3g)" % (int(diff.sum()), diff.size, float(np.nanmax(np.abs(g - c))))
+    # the blocks really see what configs[2] names: floor and wall blocks are textured (pixels differ within a flat-shaded region)
+    for (x, y) in ((12, 30), (10, 14)):
+        blk = c[32 * y:32 * y + 32, 32 * x:32 * x + 32, :3]
+        assert np.nanstd(blk) > 1e-4
+
+
+def test_config2_full_frame_properties(gpu_ctx, head_textured_gpu):
+    """One full 1920x1080 x 256 spp pass (531 M samples) twice: bit-identical run to run, weight exactly 1 in every pixel (Gaussian mode
+    adds a normalised, saturated colour per pixel, reference :780-787), all values finite and in [0,1], ray counter reproducible."""
+    cam, lights = scene.make_camera(width=W, height=H), [scene.make_light()]
+    prm = _c2_params(3)
+    nbytes = W * H * 16
+    d = gpu_ctx.malloc(nbytes)
+    imgs, rays = [], []
+    for _ in range(2):
+        capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, d, 0, nbytes))
+        gpu_ctx.reset_counters()
+        head_textured_gpu.render_pass_dev(prm, cam, lights, d)
+        gpu_ctx.sync()
+        rays.append(gpu_ctx.counters()["rays"])
+        imgs.append(gpu_ctx.d2h(d, (H, W, 4), np.float32))
+    gpu_ctx.free(d)
+    a, b = imgs
+    assert np.array_equal(_bits(a), _bits(b)) and rays[0] == rays[1]
+    nan_px = np.isnan(a[..., :3]).any(-1)  # hits on head.obj's 16 degenerate-uv triangles (see _differing_words): a handful of pixels
+    assert nan_px.sum() < 2e-4 * W * H and not np.isinf(a).any()
+    assert (a[..., 3] == 1.0).all() and np.nanmin(a[..., :3]) >= 0.0 and np.nanmax(a[..., :3]) <= 1.0
+    samples = W * H * SPP
+    assert 3.0 < rays[0] / samples < 8.0, "rays per sample %.2f" % (rays[0] / samples)
+    # lit head in the middle, darker towards the corners: a crude picture check that needs no oracle
+    assert np.nanmean(a[400:700, 800:1100, :3]) > 2 * np.nanmean(a[:100, :100, :3]) > 0
+
+
+def test_textured_gaussian_image_within_tolerance_of_libm_oracle(gpu_ctx, head_textured_gpu, head_textured, oracle):
+    """north_star's image criterion against what the reference calls (libm pow/exp/sin/cos): 240x135, 64 spp, textures + normal maps +
+    Gaussian AA + roulette; resolved picture within RMSE 2e-3 per pixel and 1e-3 relative mean luminance of the libm oracle's."""
+    w, h = 240, 135
+    cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]
+    prm = _c2_params(11, w, h, 64)
+    g = head_textured_gpu.render_pass(prm, cam, lights)
+    img = gpu_ctx.resolve(g)
+    c, _ = oracle.render_pass(head_textured, prm, cam, lights, nthreads=8, libm=True)
+    ref = oracle.resolve(c, libm=True)
+    assert np.array_equal(np.isnan(img), np.isnan(ref)) and np.isnan(ref).sum() < 40  # NaN pixels (see _differing_words) coincide
+    rmse = float(np.sqrt(np.nanmean((img[..., :3] - ref[..., :3]) ** 2)))
+    lum = lambda a: float(np.nanmean((a[..., :3] * np.array([0.299, 0.587, 0.114], np.float32)).sum(-1)))  # noqa: E731
+    assert rmse < 2e-3, "per-pixel RMSE vs libm oracle %.3g" % rmse
+    assert abs(lum(img) - lum(ref)) / lum(ref) < 1e-3
+    # and bit-exact against the oracle's portable-math variant on the same frame
+    cp, _ = oracle.render_pass(head_textured, prm, cam, lights, nthreads=8)
+    assert not _differing_words(g, cp).any()
+
+
+def _random_rays(n, seed, lo, hi, length):
+    rng = np.random.RandomState(seed)
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d *= (length / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d.astype(np.float32)
+
+
+def test_config4_ten_million_triangles_dof_exact(gpu_ctx, oracle):
+    """configs[4] at its full 10 M triangles: host SAH build (parallel over subtrees, ~15 s), scene upload (1.2 GB of records), then
+    primary rays, incoherent any-hit rays and a depth-of-field pass against the oracle on the same tree."""
+    m = scene.tetra_cloud_scene(10_000_000)
+    assert m["pos"].shape[0] == 10_000_000
+    nodes, lst, st = hostapi.bvh_build(m["pos"], True)
+    sd = dict(pos=m["pos"], nrm=m["nrm"], uv=m["uv"], mat_id=m["mat_id"], woop=hostapi.woop_from_positions(m["pos"]),
+              materials=m["materials"], textures=[], nodes=nodes, list=lst)
+    s = capi.Scene(gpu_ctx, sd)
+    try:
+        assert s.stats()["depth"] == st["true_depth"] > 25  # deeper than the LDS stack: deferred rays + overflow variants run
+        w, h = 192, 108
+        cam, lights = scene.tetra_cloud_view(w, h)
+        o, d = oracle.gen_primary(cam, w, h)
+        c = oracle.raycast(sd, o, d, False, nthreads=8)
+        assert (c["id"] >= 0).mean() > 0.5
+        g = s.raycast(o, d, False)
+        assert np.array_equal(g["id"], c["id"])
+        for k in "tuv":
+            assert np.array_equal(g[k].view(np.uint32), c[k].view(np.uint32)), k
+        ro, rd = _random_rays(40000, 5, [-0.6, -0.6, -0.6], [0.6, 0.6, 0.6], 1.5)
+        assert np.array_equal(s.raycast(ro, rd, True)["id"], oracle.raycast(sd, ro, rd, True, nthreads=8)["id"])
+        w, h = 64, 64
+        cam, lights = scene.tetra_cloud_view(w, h)
+        prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=True, depth_of_field=True, aperture=0.01,
+                                focal_distance=1.2, pass_seed=6)
+        gi = s.render_pass(prm, cam, lights)
+        ci, _ = oracle.render_pass(sd, prm, cam, lights, nthreads=8)
+        assert ci[..., :3].max() > 0 and np.array_equal(_bits(gi), _bits(ci)), "10 M-triangle DoF render differs"
+    finally:
+        s.close()
