@@ -1,51 +1,79 @@
 #!/usr/bin/env python3
-"""bench.py -- Mrays/s and samples/s of the hot path on N MI355X (one process per GPU, torch.distributed over RCCL).
+"""bench.py -- Mrays/s and samples/s of the hot path on N MI355X (one process per GPU).
 
-Headline workload (`value`, Mrays/s) = BASELINE.json configs[1]: head.obj, 1920x1080, one pixel-centre primary ray per
-pixel traced closest-hit (RayTracer::raycast, occlusion=false) plus one shadow ray per primary hit traced any-hit
-(occlusion=true); rays are generated on the device, every buffer is resident in HBM before the timed region.  One "step" =
-one such frame: gen_primary -> raycast(closest) -> gen_shadow -> raycast(any-hit).  1 ray = 1 raycast() call, like the
-reference's counter (reference src/RayTracer.cpp:192, src/PathTraceRenderer.cpp:884-897).
-N>1: the path shards by image tiles with no data-path exchange, so every rank traces its own 1920x1080 frame (weak
-scaling); ranks only meet in the timing barriers and the ray-count sum.
+Headline workload (`value`, Mrays/s) = BASELINE.json configs[1]: head.obj, 1920x1080, one pixel-centre primary ray per pixel traced
+closest-hit (RayTracer::raycast, occlusion=false) plus one shadow ray per primary hit traced any-hit (occlusion=true); rays are
+generated on the device, every buffer is resident in HBM before the timed region.  One "step" = one such frame:
+gen_primary -> raycast(closest) -> gen_shadow -> raycast(any-hit).  1 ray = 1 raycast() call, like the reference's counter
+(reference src/RayTracer.cpp:192, src/PathTraceRenderer.cpp:884-897).  N>1: the path shards by image tiles with no data-path
+exchange, so every rank traces its own 1920x1080 frame (weak scaling); ranks only meet in the timing barriers and the
+ray-count sum.
 
-Second leg (`path_trace`, samples/s) = BASELINE.json configs[2]: head.obj full path trace 1920x1080, 256 spp, Gaussian AA,
-bilinear textures + tangent-space normal maps (procedural stand-ins for the maps, see scene.head_standin_textures),
-Russian roulette after 1 bounce (p = 0.2).  One pass = PathTraceRenderer's pass over all 32x32 blocks.  With N>1 the SAME
-frame is sharded by blocks (rank r renders blocks r, r+N, ...) and the accumulation tiles are gathered over RCCL
-(pathtracer_amd.multigpu.TileGather), inside the timed region: that leg is strong scaling and says so.
+Second leg (`path_trace`, samples/s) = BASELINE.json configs[2]: head.obj full path trace 1920x1080, 256 spp, Gaussian AA, bilinear
+textures + tangent-space normal maps (scene.head_textures: the reference's own floor and wall maps, stand-ins for its three missing
+maps), Russian roulette after 1 bounce (p = 0.2).  One pass = PathTraceRenderer's pass over all 32x32 blocks.  With N>1 the SAME frame
+is sharded by blocks (rank r renders blocks r, r+N, ...) and the tiles are gathered inside the timed region by
+ptgpu_gather_tiles_dev (ncclAllGather over xGMI behind the C ABI): that leg is strong scaling and says so.
 
-The CPU oracle (oracle/) is used ONLY for the cpu_baseline legs (rank 0, N=1) -- never in the measured path.
-"""
+Launch: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run, one per GPU) before touching a GPU; under
+torch.distributed.run (WORLD_SIZE set by the launcher) it is one of the ranks.  The CPU oracle (oracle/) is used ONLY for the
+cpu_baseline legs (rank 0, N=1) -- never in the measured path."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from pathtracer_amd import capi, hostapi, multigpu, scene  # noqa: E402
-
 W, H = 1920, 1080
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-GATHER_PEAK_GBS, GATHER_INCOHERENT_GBS = 37950.0, 14230.0  # measured: tools/l1_gather_peak.hip, profiles/r01_n_l1_gather_peak.jsonl
 PT_SPP = 256
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md "HBM": 8.0 TB/s spec
+L2_GATHER_PEAK_GBS = 36900.0  # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate, 36.9 TB/s with the L1-reuse contribution
+# measured on this GPU by tools/l1_gather_peak.hip (profiles/r01_n_l1_gather_peak.jsonl): 64-byte records gathered per lane from cache
+GATHER_COHERENT_GBS, GATHER_INCOHERENT_GBS = 37950.0, 14230.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pt-passes", type=int, default=3, help="timed passes of the path-trace leg (0 = skip the leg)")
+    ap.add_argument("--pt-spp", type=int, default=PT_SPP)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the large-scene legs (atrium 262k triangles, 10 M-triangle cloud; N=1 only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the measured configuration); gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (nothing in this process has touched a GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def build_head_scene(textured=False):
     """Product-side scene construction: triangle array + Woop data + SAH BVH from the C++ host classes (no oracle)."""
+    from pathtracer_amd import hostapi, scene
     mesh = scene.load_ptmesh()
     woop = hostapi.woop_from_positions(mesh["pos"])
     nodes, lst, stats = hostapi.bvh_build(mesh["pos"], sah=True)
-    textures, index = scene.head_standin_textures(mesh) if textured else ([], None)
+    textures, index, labels = scene.head_textures(mesh) if textured else ([], None, {})
     sd = dict(pos=mesh["pos"], nrm=mesh["nrm"], uv=mesh["uv"], mat_id=mesh["mat_id"], woop=woop,
               materials=scene.mesh_materials(mesh, textured=textured, texture_index=index), textures=textures, nodes=nodes, list=lst)
+    sd["texture_labels"] = labels
     return sd, stats
 
 
@@ -54,23 +82,49 @@ def algorithmic_bytes(ctr, rays):
     return 64 * ctr["node_visits"] + 52 * ctr["tri_tests"] + 44 * rays
 
 
+def pmc_profile():
+    """Per-kernel counters of the committed rocprofv3 passes (profiles/traffic.json, written by tools/summarize_profiles.py from
+    separate --pmc runs of tools/profile_kernels.py = the same launches as this bench): HBM bytes per launch (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes, + WRITE_SIZE), L2 hit rate, VALU utilisation."""
+    f = os.path.join(ROOT, "profiles", "traffic.json")
+    return json.load(open(f)) if os.path.exists(f) else {}
+
+
+def roofline(kernel, alg_bytes, ms, prof, note):
+    """The bound that binds a traversal kernel is the cache-side gather of 64-byte records (the scene is L2-resident), so `peak` is the
+    guide's aggregate L2 rate; the HBM view the contract names is kept beside it: `hbm` = counter bytes per launch / time / 8 TB/s."""
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    traffic = prof.get("hbm_bytes_per_launch")
+    out = {"kernel": kernel, "bound": "l2-gather", "achieved": achieved, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / L2_GATHER_PEAK_GBS, "traffic": traffic, "algorithmic_GBps": achieved, "ms_per_launch": ms,
+           "algorithmic_bytes_per_launch": alg_bytes,
+           "hbm": {"achieved": (traffic / (ms * 1e-3) / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                   "algorithmic_over_hbm_peak": achieved / HBM_PEAK_GBS},
+           "l2_hit": prof.get("l2_hit_rate"), "valu_util": prof.get("valu_active_frac_of_wave_cycles"),
+           "valu_lane_util": prof.get("valu_lane_utilisation"),
+           "measured_gather_ceiling": {"coherent": GATHER_COHERENT_GBS, "incoherent": GATHER_INCOHERENT_GBS, "unit": "GB/s",
+                                       "frac_of_coherent": achieved / GATHER_COHERENT_GBS},
+           "note": note}
+    return out
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pt-passes", type=int, default=3, help="timed passes of the path-trace leg (0 = skip the leg)")
-    ap.add_argument("--pt-spp", type=int, default=PT_SPP)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL (the measured configuration); gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks")
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from pathtracer_amd import capi, scene
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     ndev = torch.cuda.device_count()
     if args.backend == "nccl" and local_rank >= ndev:
         raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible: one rank per GPU" % (local_rank, ndev))
@@ -128,7 +182,7 @@ def main():
     cs = ctx.counters()
     ctx.enable_counters(False)
     rays_per_step = n + n_shadow
-    bytes_primary = algorithmic_bytes(cp, n)
+    bytes_primary, bytes_shadow = algorithmic_bytes(cp, n), algorithmic_bytes(cs, n)
 
     for _ in range(args.warmup):
         step()
@@ -155,13 +209,19 @@ def main():
     gscene.close()
 
     pt = path_trace_leg(args, ctx, stream, dev, red_dev, rank, world) if args.pt_passes > 0 else None
+    extra = extra_legs(ctx, stream, dev) if (world == 1 and not args.no_extra) else None
 
     if rank == 0:
-        achieved = bytes_primary / (closest_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("k_raycast_closest_hbm_bytes_per_launch")
+        prof = pmc_profile()
+        # the step's dominant kernel carries the line's roofline; the other traversal kernel is reported beside it
+        rl_any = roofline("k_raycast_step<any-hit>", bytes_shadow, anyhit_ms, prof.get("k_raycast_anyhit", {}),
+                          "algorithmic bytes (64 B/node visit + 52 B/triangle test + 44 B/ray, SURVEY.md 8d) of one launch = 2,073,600 shadow rays / "
+                          "HIP-event time of the launch.  head.obj's 1.6 MB of records never leave L2 (`l2_hit`, `traffic` = rays in + hit "
+                          "ids out), so the HBM roofline does not bind; the record gather from cache does: `peak` = the guide's aggregate "
+                          "L2 rate.  Any-hit runs below closest-hit because its rays end at different depths (`valu_lane_util`).")
+        rl_closest = roofline("k_raycast_step<closest-hit>", bytes_primary, closest_ms, prof.get("k_raycast_closest", {}),
+                              "same accounting for the 2,073,600 primary rays of the step")
+        dominant, other = (rl_any, rl_closest) if anyhit_ms >= closest_ms else (rl_closest, rl_any)
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -173,25 +233,16 @@ def main():
             "kernels_ms": {"raycast_closest": closest_ms, "raycast_anyhit": anyhit_ms},
             "per_ray": {"primary_nodes": cp["node_visits"] / n, "primary_tris": cp["tri_tests"] / n,
                         "shadow_nodes": cs["node_visits"] / n, "shadow_tris": cs["tri_tests"] / n},
-            "roofline": {"kernel": "k_raycast_step<closest-hit>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "algorithmic bytes (64 B/node visit + 52 B/triangle test + 44 B/ray); head.obj's 1.6 MB of "
-                                 "nodes+triangles is L2-resident, so frac measures traversal rate, not HBM pressure (`traffic` is what "
-                                 "reaches HBM: the rays in and the hit records out). Measured limiter: the vector L1 data path, "
-                                 "64 B per lane per step (TD_TD_BUSY 66 % of kernel cycles, L1 hit rate 98 %: profiles/l1a_pmc_summary.json)",
-                         "cache_gather": {"achieved": achieved, "peak": GATHER_PEAK_GBS, "peak_incoherent": GATHER_INCOHERENT_GBS,
-                                          "unit": "GB/s", "frac": achieved / GATHER_PEAK_GBS,
-                                          "note": "the bound that applies: 64-byte records gathered per lane from cache, measured on this "
-                                                  "GPU by tools/l1_gather_peak.hip (profiles/r01_n_l1_gather_peak.jsonl): `peak` with >= 4 "
-                                                  "neighbouring lanes on the same record (64 B/clk/CU), `peak_incoherent` with every "
-                                                  "lane on its own record; same rate from a 16 KiB and a 4 MiB table"}},
+            "roofline": dominant, "roofline_other_kernel": other,
         }
         if pt:
             out["path_trace"] = pt
+        if extra:
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, cam, light)
             if pt:
-                out["path_trace"]["cpu_baseline"] = cpu_baseline_path_trace(sd)
+                out["path_trace"]["cpu_baseline"] = cpu_baseline_path_trace(args.pt_spp)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
@@ -200,31 +251,34 @@ def main():
 
 def path_trace_leg(args, ctx, stream, dev, red_dev, rank, world):
     """configs[2]: full path trace of the 1080p head frame; blocks dealt round-robin over ranks, tiles gathered over RCCL."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from pathtracer_amd import capi, multigpu, scene
     sd, _ = build_head_scene(textured=True)
     gscene = capi.Scene(ctx, sd)
     cam, lights = scene.make_camera(width=W, height=H), [scene.make_light()]
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device=dev)
-    tg = multigpu.TileGather(W, H, rank, world, dev, stage_on_cpu=(args.backend == "gloo"))
+    if args.backend == "nccl":
+        tg = multigpu.DeviceTileGather(ctx, W, H, rank, world)  # ptgpu_gather_tiles_dev: pack + ncclAllGather + unpack on the stream
+    else:
+        tg = multigpu.TileGather(W, H, rank, world, dev, ctx=ctx)  # rehearsal: device pack / unpack around a gloo all_gather
 
-    def params(seed):
-        return scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=args.pt_spp, sobol_block=False, bilinear=True, normal_mapped=True,
+    def params(seed, spp=args.pt_spp):
+        return scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=spp, sobol_block=False, bilinear=True, normal_mapped=True,
                                  filter_width=1.5, termination_prob=0.2, pass_seed=seed)
-
-    def one_pass(seed):
-        gscene.render_pass_dev(params(seed), cam, lights, accum.data_ptr(), block_begin=rank, block_stride=world)
-        tg.gather(accum)
 
     # traversal work per ray for the roofline of the integrator kernel: one counted low-spp pass
     ctx.enable_counters(True)
     ctx.reset_counters()
-    p = params(1000)
-    p.num_aa_rays = 4
-    gscene.render_pass_dev(p, cam, lights, accum.data_ptr(), block_begin=rank, block_stride=world)
+    gscene.render_pass_dev(params(1000, 4), cam, lights, accum.data_ptr(), block_begin=rank, block_stride=world)
     c = ctx.counters()
     ctx.enable_counters(False)
     bytes_per_ray = algorithmic_bytes(c, c["rays"]) / max(c["rays"], 1)
     accum.zero_()
-    one_pass(999)  # warm-up (also sizes the workspace)
+    gscene.render_pass_dev(params(999), cam, lights, accum.data_ptr(), block_begin=rank, block_stride=world)  # warm-up (sizes the workspace)
+    tg.gather(accum)
     accum.zero_()
     ctx.reset_counters()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.pt_passes)]
@@ -249,18 +303,97 @@ def path_trace_leg(args, ctx, stream, dev, red_dev, rank, world):
     elapsed, rays = float(tmax.item()), int(rays.item())
     render_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     local_rays = ctx.counters()["rays"]
+    dropped = ctx.spill_status()["dropped"]
+    if isinstance(tg, multigpu.DeviceTileGather):
+        tg.close()
     gscene.close()
     samples = W * H * args.pt_spp * args.pt_passes
-    achieved = bytes_per_ray * (local_rays / args.pt_passes) / (render_ms * 1e-3) / 1e9
-    return {"workload": "head.obj full path trace %dx%d, %d spp, Gaussian AA, bilinear textures + normal maps (procedural stand-in maps), "
-                        "RR after 1 bounce p=0.2 (BASELINE configs[2])" % (W, H, args.pt_spp),
-            "passes": args.pt_passes, "scaling": "strong" if world > 1 else "n/a", "tile_gather": ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)") + " all_gather of packed 32x32-block tiles" if world > 1 else "none",
+    prof = pmc_profile().get("k_integrate", {})
+    spp_scale = args.pt_spp / float(prof.get("spp", args.pt_spp)) if prof else 1.0
+    if prof.get("hbm_bytes_per_launch"):
+        prof = dict(prof, hbm_bytes_per_launch=prof["hbm_bytes_per_launch"] * spp_scale)
+    rl = roofline("k_integrate (+ k_accum_gauss)", bytes_per_ray * (local_rays / args.pt_passes), render_ms, prof,
+                  "algorithmic traversal bytes per ray x rays of one pass / HIP-event time of the pass (integrator + accumulation launches); bounce "
+                  "rays are incoherent, so the per-lane gather ceiling that applies is `measured_gather_ceiling.incoherent`.  `traffic` = counter "
+                  "bytes of the profiled %s-spp launch scaled to %d spp: per-sample radiance written once (16 B/sample) and read once by the "
+                  "accumulation, plus texel gathers from the 61 MB of maps that miss the 4 MB L2 (served by the Infinity Cache)" %
+                  (prof.get("spp", "?"), args.pt_spp))
+    rl["frac_of_incoherent_ceiling"] = rl["achieved"] / GATHER_INCOHERENT_GBS
+    labels = sd["texture_labels"]
+    return {"workload": "head.obj full path trace %dx%d, %d spp, Gaussian AA (filter 1.5), bilinear textures + normal maps, RR after 1 bounce p=0.2 "
+                        "(BASELINE configs[2]); maps 1600x1600: %s" % (W, H, args.pt_spp, ", ".join("%s = %s" % kv for kv in sorted(labels.items()))),
+            "passes": args.pt_passes, "scaling": "strong" if world > 1 else "n/a",
+            "tile_gather": (("ptgpu_gather_tiles_dev: ncclAllGather (RCCL) of packed 32x32-block tiles" if args.backend == "nccl" else
+                             "device pack/unpack + gloo all_gather (rehearsal)") if world > 1 else "none"),
             "samples_per_s": samples / elapsed, "Mrays_per_s": rays / elapsed / 1e6, "rays_per_sample": rays / samples,
-            "ms_per_pass": elapsed / args.pt_passes * 1e3, "render_ms_per_pass_rank0": render_ms,
+            "ms_per_pass": elapsed / args.pt_passes * 1e3, "render_ms_per_pass_rank0": render_ms, "dropped_samples": dropped,
             "per_ray": {"nodes": c["node_visits"] / max(c["rays"], 1), "tris": c["tri_tests"] / max(c["rays"], 1), "bytes": bytes_per_ray},
-            "roofline": {"kernel": "k_integrate (+ accumulate)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "algorithmic traversal bytes per ray x rays per pass / device time of the pass; scene is L2-resident"}}
+            "roofline": rl}
+
+
+def extra_legs(ctx, stream, dev):
+    """Large-scene stand-ins on one GPU (N=1 only; their multi-GPU configurations are the driver's to launch): BASELINE configs[3]
+    (Crytek Sponza is not in the reference checkout: scene.atrium_scene, ~262k triangles, 3840x2160) and configs[4]
+    (scene.tetra_cloud_scene, 10 M triangles, 1080p, depth of field).  Primary-ray frame + one low-spp path-trace pass each."""
+    import numpy as np
+    import torch
+
+    from pathtracer_amd import capi, hostapi, scene
+    out = []
+    for name, make, view, (w, h), spp, dof in (
+            ("atrium 262k triangles 3840x2160 (procedural stand-in for BASELINE configs[3] Sponza)", scene.atrium_scene, scene.atrium_view,
+             (3840, 2160), 4, False),
+            ("tetra cloud 10 M triangles 1920x1080 + depth of field (BASELINE configs[4])", lambda: scene.tetra_cloud_scene(10_000_000),
+             scene.tetra_cloud_view, (1920, 1080), 4, True)):
+        m = make()
+        t0 = time.perf_counter()
+        nodes, lst, st = hostapi.bvh_build(m["pos"], True)
+        build_s = time.perf_counter() - t0
+        sd = dict(pos=m["pos"], nrm=m["nrm"], uv=m["uv"], mat_id=m["mat_id"], woop=hostapi.woop_from_positions(m["pos"]),
+                  materials=m["materials"], textures=[], nodes=nodes, list=lst)
+        s = capi.Scene(ctx, sd)
+        cam, lights = view(w, h)
+        n = w * h
+        o, d = (torch.empty(n * 3, dtype=torch.float32, device=dev) for _ in range(2))
+        t, u, v = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
+        hid = torch.empty(n, dtype=torch.int32, device=dev)
+        P = lambda x: x.data_ptr()  # noqa: E731
+        ctx.gen_primary_dev(cam, w, h, P(o), P(d))
+        ctx.enable_counters(True)
+        ctx.reset_counters()
+        s.raycast_dev(P(o), P(d), n, False, P(hid), P(t), P(u), P(v))
+        c = ctx.counters()
+        ctx.enable_counters(False)
+        for _ in range(3):
+            s.raycast_dev(P(o), P(d), n, False, P(hid), P(t), P(u), P(v))
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 10
+        ev[0].record(stream)
+        for _ in range(reps):
+            s.raycast_dev(P(o), P(d), n, False, P(hid), P(t), P(u), P(v))
+        ev[1].record(stream)
+        torch.cuda.synchronize(dev)
+        ms = ev[0].elapsed_time(ev[1]) / reps
+        alg = algorithmic_bytes(c, n)
+        accum = torch.zeros(n * 4, dtype=torch.float32, device=dev)
+        prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=spp, sobol_block=True, depth_of_field=dof, aperture=0.01,
+                                focal_distance=1.2, pass_seed=1)
+        s.render_pass_dev(prm, cam, lights, P(accum))  # warm-up
+        ctx.reset_counters()
+        ev[0].record(stream)
+        s.render_pass_dev(prm, cam, lights, P(accum))
+        ev[1].record(stream)
+        torch.cuda.synchronize(dev)
+        pt_ms = ev[0].elapsed_time(ev[1])
+        rays = ctx.counters()["rays"]
+        out.append({"workload": name, "triangles": int(m["pos"].shape[0]), "bvh_nodes": int(nodes.shape[0]), "host_sah_build_s": build_s,
+                    "primary_Mrays_per_s": n / (ms * 1e-3) / 1e6, "primary_ms": ms,
+                    "per_ray": {"nodes": c["node_visits"] / n, "tris": c["tri_tests"] / n, "bytes": alg / n},
+                    "primary_algorithmic_GBps": alg / (ms * 1e-3) / 1e9, "primary_frac_of_l2_gather_peak": alg / (ms * 1e-3) / 1e9 / L2_GATHER_PEAK_GBS,
+                    "path_trace": {"spp": spp, "samples_per_s": n * spp / (pt_ms * 1e-3), "Mrays_per_s": rays / (pt_ms * 1e-3) / 1e6, "ms": pt_ms}})
+        s.close()
+        del o, d, t, u, v, hid, accum, sd, m
+    return out
 
 
 def cpu_baseline(sd, cam, light):
@@ -286,19 +419,32 @@ def cpu_baseline(sd, cam, light):
             "sample": "the full configs[1] frame (2,073,600 primary + one shadow ray per hit), best of 3, the two raycast batches timed"}
 
 
-def cpu_baseline_path_trace(sd_untextured):
-    """The oracle's multithreaded pathTraceBlock loop (libm transcendentals, as the reference calls them) on a bounded sample:
-    BASELINE configs[0] (head 512x512, 16 spp, Sobol-block AA, RR) = 4.2 M samples."""
+def cpu_baseline_path_trace(spp):
+    """The oracle's multithreaded pathTraceBlock loop (libm transcendentals, as the reference calls them) on a bounded sample of the SAME
+    workload: configs[2] itself (1920x1080, same maps, Gaussian AA, normal maps, RR) on every 24th 32x32 block = 85 of the frame's 2040
+    blocks spread over the whole image."""
     from oracle import pyoracle as po
+
+    from pathtracer_amd import scene
     threads = min(16, os.cpu_count() or 1)
-    w = h = 512
-    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=16, sobol_block=True, termination_prob=0.2)
-    cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]
+    sd, _ = build_head_scene(textured=True)
+    labels = sd.pop("texture_labels")
+    prm = scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=spp, sobol_block=False, bilinear=True, normal_mapped=True,
+                            filter_width=1.5, termination_prob=0.2, pass_seed=0)
+    cam, lights = scene.make_camera(width=W, height=H), [scene.make_light()]
+    stride = 24
+    nblocks = ((W + 31) // 32) * ((H + 31) // 32)
+    pixels = 0
+    for b in range(0, nblocks, stride):
+        bx, by = (b % ((W + 31) // 32)) * 32, (b // ((W + 31) // 32)) * 32
+        pixels += min(32, W - bx) * min(32, H - by)
     t0 = time.perf_counter()
-    _, ctr = po.render_pass(sd_untextured, prm, cam, lights, nthreads=threads, libm=True)
+    _, ctr = po.render_pass(sd, prm, cam, lights, nthreads=threads, libm=True, block_begin=0, block_end=-1, block_stride=stride)
     dt = time.perf_counter() - t0
-    return {"value": w * h * 16 / dt, "unit": "samples/s", "Mrays_per_s": ctr["rays"] / dt / 1e6, "cores": threads, "kind": "port",
-            "sample": "configs[0]: head 512x512, 16 spp, Sobol-block AA, RR p=0.2, one pass (4,194,304 samples)"}
+    return {"value": pixels * spp / dt, "unit": "samples/s", "Mrays_per_s": ctr["rays"] / dt / 1e6, "cores": threads, "kind": "port",
+            "sample": "configs[2] itself (1920x1080, %d spp, Gaussian AA, same maps: %d reference files + stand-ins), every %dth 32x32 block: "
+                      "%d blocks, %d samples, one pass" % (spp, sum(1 for l in labels.values() if l == "reference file"), stride,
+                                                            len(range(0, nblocks, stride)), pixels * spp)}
 
 
 if __name__ == "__main__":

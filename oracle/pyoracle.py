@@ -149,15 +149,15 @@ def gen_shadow(sd, light, orig, direction, hit):
     return so, sdir, valid
 
 
-def render_pass(sd, params, cam, lights, accum=None, nthreads=1, libm=False, block_begin=0, block_end=-1):
-    """One pass of pathTraceBlock over blocks [block_begin, block_end) accumulated into accum [h,w,4]."""
+def render_pass(sd, params, cam, lights, accum=None, nthreads=1, libm=False, block_begin=0, block_end=-1, block_stride=1):
+    """One pass of pathTraceBlock over blocks block_begin, block_begin + block_stride, ... < block_end accumulated into accum [h,w,4]."""
     desc, keep = make_scene_desc(sd)
     if accum is None:
         accum = np.zeros((params.height, params.width, 4), np.float32)
     larr = (Light * len(lights))(*lights)
     ctr = Counters()
-    lib().pto_render_pass(C.byref(desc), C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), accum.ctypes.data,
-                          C.byref(ctr), nthreads, int(libm), block_begin, block_end)
+    lib().pto_render_pass2(C.byref(desc), C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), accum.ctypes.data,
+                           C.byref(ctr), nthreads, int(libm), block_begin, block_end, block_stride, None, 0, None)
     return accum, dict(rays=ctr.rays, node_visits=ctr.node_visits, tri_tests=ctr.tri_tests)
 
 

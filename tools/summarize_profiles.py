@@ -54,16 +54,23 @@ def main():
     keep = {k: v for k, v in out.items() if k.startswith("k_")}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(keep, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    # what bench.py reads: one entry per kernel of the bench line's rooflines
     traffic = {}
-    for k, v in keep.items():
-        if k.startswith("k_raycast_step<false") and "hbm_bytes_corrected" in v:
-            traffic["k_raycast_closest_hbm_bytes_per_launch"] = v["hbm_bytes_corrected"]
-            traffic["k_raycast_closest_hbm_bytes_per_launch_raw"] = v["hbm_bytes_raw"]
-            traffic["k_raycast_closest_l2_hit_rate"] = v.get("l2_hit_rate")
-        if k.startswith("k_integrate") and "hbm_bytes_corrected" in v:
-            traffic["k_integrate_hbm_bytes_per_launch"] = v["hbm_bytes_corrected"]
-            traffic["k_integrate_l2_hit_rate"] = v.get("l2_hit_rate")
-    traffic["source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM note)" % tag
+    want = {"k_raycast_closest": "k_raycast_step<false", "k_raycast_anyhit": "k_raycast_step<true", "k_integrate": "k_integrate"}
+    fields = ("hbm_bytes_corrected", "hbm_bytes_raw", "l2_hit_rate", "valu_active_frac_of_wave_cycles", "valu_lane_utilisation",
+              "avg_duration_us", "launches", "vgpr", "lds_bytes")
+    for key, prefix in want.items():
+        for k, v in keep.items():
+            if k.startswith(prefix):
+                e = {f: v[f] for f in fields if f in v}
+                if "hbm_bytes_corrected" in e:
+                    e["hbm_bytes_per_launch"] = e["hbm_bytes_corrected"]
+                e["kernel"] = k
+                traffic[key] = e
+    if "k_integrate" in traffic:
+        traffic["k_integrate"]["spp"] = int(sys.argv[2]) if len(sys.argv) > 2 else 16  # spp of the profiled pass (tools/profile_kernels.py)
+    traffic["source"] = ("profiles/%s_pmc_summary.json: rocprofv3 --pmc passes over tools/profile_kernels.py (FETCH_SIZE / WRITE_SIZE / TCC / SQ in "
+                         "separate runs; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE KiB per MI355X_MICROARCH.md's gfx950 correction)" % tag)
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
     for k, v in sorted(keep.items()):
         print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
