@@ -201,6 +201,27 @@ int ptgpu_render_pass_dev(ptgpu_scene* scene, const ptgpu_params* params, const 
                           int32_t num_lights, int32_t block_begin, int32_t block_end, int32_t block_stride, float* d_accum);
 int ptgpu_render_pass(ptgpu_scene* scene, const ptgpu_params* params, const ptgpu_camera* cam, const ptgpu_light* lights,
                       int32_t num_lights, int32_t block_begin, int32_t block_end, int32_t block_stride, float* accum);
+/* ---- the reference's static per-sample functions (src/PathTraceRenderer.hpp:97-102), evaluated by the same device code the render pass runs.
+ * ptgpu_trace_samples[_dev]: Vec3f tracePath(x, y, ctx, samplerBase, R, ...) (src/PathTraceRenderer.cpp:236-551), or traceWhitted
+ * (:553-660) when params->whitted, for n arbitrary samples: xy [n][2] clip-space position, sampler_base [n] Sobol index base,
+ * rng_state [n][2] = (key, counter) of the sample's random stream (this build's counter-based stand-in for FW::Random: key =
+ * the hashed seed words, counter = draws consumed so far).  out [n][4] floats: radiance rgb, and in the 4th word the BITS of the
+ * stream's counter after the call (the reference advances the caller's Random by reference).  params->width/height are not used
+ * (the camera's invP carries the image size).  lights: HOST array.  _dev: device arrays, work only enqueued. */
+int ptgpu_trace_samples_dev(ptgpu_scene* scene, const ptgpu_params* params, const ptgpu_camera* cam, const ptgpu_light* lights,
+                            int32_t num_lights, int64_t n, const float* d_xy, const int32_t* d_sampler_base, const uint32_t* d_rng_state,
+                            float* d_out);
+int ptgpu_trace_samples(ptgpu_scene* scene, const ptgpu_params* params, const ptgpu_camera* cam, const ptgpu_light* lights, int32_t num_lights,
+                        int64_t n, const float* xy, const int32_t* sampler_base, const uint32_t* rng_state, float* out);
+/* void getTextureParameters(hit, diffuse, n, specular) (src/PathTraceRenderer.cpp:75-181) for n hits given as (triangle index, u, v);
+ * uses params->bilinear and params->normal_mapped.  HOST arrays; out [n][9] = diffuse rgb, shading normal, specular rgb. */
+int ptgpu_texture_parameters_batch(ptgpu_scene* scene, const ptgpu_params* params, int64_t n, const int32_t* tri, const float* u,
+                                   const float* v, float* out_diffuse_normal_specular);
+/* int getLightToSample(ctx, pos, R) (src/PathTraceRenderer.cpp:183-210) for n positions [n][3], each with its own stream state
+ * rng_state [n][2] (key, counter).  HOST arrays; out [n][2] = chosen light, counter after the call (one draw when num_lights > 1). */
+int ptgpu_light_to_sample_batch(ptgpu_context* ctx, const ptgpu_light* lights, int32_t num_lights, int64_t n, const float* pos,
+                                const uint32_t* rng_state, int32_t* out_index_and_counter);
+
 /* PathTraceRenderer::updatePicture (src/PathTraceRenderer.cpp:855-871): out = (pow(rgb / w, 1/2.2), w / w) per pixel, w == 0
  * pixels pass through undivided.  Both pointers are DEVICE pointers, [height][width][4] floats. */
 int ptgpu_resolve_dev(ptgpu_context* ctx, const float* d_accum, int32_t width, int32_t height, float* d_out_rgba);

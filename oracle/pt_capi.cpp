@@ -264,4 +264,46 @@ void pto_trace_path(const pto_scene* s, const pto_params* p, const pto_camera* c
     if (ctr) { ctr->rays += c.rays; ctr->node_visits += c.node_visits; ctr->tri_tests += c.tri_tests; }
 }
 
+// tracePath / traceWhitted for n samples given as tracePath's own arguments: clip-space (x, y), Sobol base, the random stream's
+// (key, counter) state.  out [n][4]: radiance rgb + the counter after the call as bits (the device's ptgpu_trace_samples layout).
+void pto_trace_samples(const pto_scene* s, const pto_params* p, const pto_camera* cam, const pto_light* lights, int nl, int64_t n,
+                       const float* xy, const int32_t* sampler_base, const uint32_t* rng_state, int libm, float* out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    parallel_for(n, 256, nthreads, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; ++i) {
+            Rng R = Rng::from_state(rng_state[2 * i], rng_state[2 * i + 1]);
+            Counters c;
+            V3 r;
+            const float x = xy[2 * i], y = xy[2 * i + 1];
+            if (p->whitted)
+                r = libm ? trace_whitted<LibmMath>(*s, *p, *cam, lights, nl, x, y, sampler_base[i], R, c)
+                         : trace_whitted<PtmMath>(*s, *p, *cam, lights, nl, x, y, sampler_base[i], R, c);
+            else
+                r = libm ? trace_path<LibmMath>(*s, *p, *cam, lights, nl, x, y, sampler_base[i], R, c)
+                         : trace_path<PtmMath>(*s, *p, *cam, lights, nl, x, y, sampler_base[i], R, c);
+            out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z;
+            std::memcpy(out + 4 * i + 3, &R.ctr, 4);
+        }
+    });
+}
+uint32_t pto_rng_key(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) { return Rng(k0, k1, k2, k3).key; }
+// getTextureParameters for n hits (triangle, u, v); out [n][9] = diffuse, normal, specular
+void pto_texture_parameters(const pto_scene* s, const pto_params* p, int64_t n, const int32_t* tri, const float* u, const float* v, float* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        Hit h{tri[i], 0.0f, u[i], v[i], V3{}, V3{}, V3{}};
+        V3 d, nn, sp;
+        get_texture_parameters<PtmMath>(*s, *p, h, d, nn, sp);
+        float* o = out + i * 9;
+        o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = nn.x; o[4] = nn.y; o[5] = nn.z; o[6] = sp.x; o[7] = sp.y; o[8] = sp.z;
+    }
+}
+// getLightToSample for n positions; out [n][2] = light index, stream counter after the call
+void pto_light_to_sample(const pto_light* lights, int nl, int64_t n, const float* pos, const uint32_t* rng_state, int32_t* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        Rng R = Rng::from_state(rng_state[2 * i], rng_state[2 * i + 1]);
+        out[2 * i] = get_light_to_sample(ld3(pos + 3 * i), lights, nl, R);
+        out[2 * i + 1] = (int32_t)R.ctr;
+    }
+}
+
 }  // extern "C"

@@ -37,6 +37,7 @@ struct Rng {
     Rng(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) : ctr(0) {
         key = mix(k3 + mix(k2 + mix(k1 + mix(k0 + 0x9E3779B9u))));
     }
+    static Rng from_state(uint32_t key_, uint32_t ctr_) { Rng r(0, 0, 0, 0); r.key = key_; r.ctr = ctr_; return r; }
     uint32_t at(uint32_t n) const { return mix(key ^ mix(n * 0x9E3779B9u + 0x7F4A7C15u)); }
     uint32_t u32() { return at(ctr++); }
     uint32_t peek_u32() const { return at(ctr); }

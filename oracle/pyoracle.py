@@ -56,6 +56,12 @@ def lib():
         L.pto_resolve.argtypes = [_P, C.c_int, C.c_int, _P, C.c_int]
         L.pto_trace_path.argtypes = [C.POINTER(SceneDesc), C.POINTER(Params), C.POINTER(Camera), _P, C.c_int, C.c_float,
                                      C.c_float, C.c_int, _P, C.c_int, _P, C.POINTER(Counters)]
+        L.pto_trace_samples.argtypes = [C.POINTER(SceneDesc), C.POINTER(Params), C.POINTER(Camera), _P, C.c_int, C.c_int64, _P, _P, _P,
+                                        C.c_int, _P, C.c_int]
+        L.pto_rng_key.restype = C.c_uint32
+        L.pto_rng_key.argtypes = [C.c_uint32] * 4
+        L.pto_texture_parameters.argtypes = [C.POINTER(SceneDesc), C.POINTER(Params), C.c_int64, _P, _P, _P, _P]
+        L.pto_light_to_sample.argtypes = [_P, C.c_int, C.c_int64, _P, _P, _P]
         L.pto_math_probe.argtypes = [C.c_int, _P, _P, _P, C.c_int, C.c_int]
         L.pto_woop_from_vertices.argtypes = [_P, _P, _P, _P]
         L.pto_intersect_woop.argtypes = [_P, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -172,6 +178,40 @@ def render_pass_tiles(sd, params, cam, lights, accum, block_begin, block_stride,
     lib().pto_render_pass2(C.byref(desc), C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), accum.ctypes.data,
                            C.byref(ctr), nthreads, 0, block_begin, -1, block_stride, foreign.ctypes.data, foreign_cap, C.byref(nf))
     return accum, foreign[: nf.value].copy(), dict(rays=ctr.rays, node_visits=ctr.node_visits, tri_tests=ctr.tri_tests)
+
+
+def rng_key(k0, k1, k2, k3):
+    """Key of the counter-based random stream seeded with four words (the stand-in for FW::Random(seed))."""
+    return lib().pto_rng_key(int(k0), int(k1), int(k2), int(k3))
+
+
+def trace_samples(sd, params, cam, lights, xy, sampler_base, rng_state, libm=False, nthreads=1):
+    """tracePath / traceWhitted per sample -> (radiance [n,3], stream counters after the call [n] uint32)."""
+    desc, keep = make_scene_desc(sd)
+    xy, base = _f32(xy).reshape(-1, 2), np.ascontiguousarray(sampler_base, np.int32)
+    rng = np.ascontiguousarray(rng_state, np.uint32).reshape(-1, 2)
+    n = xy.shape[0]
+    out = np.empty((n, 4), np.float32)
+    larr = (Light * len(lights))(*lights)
+    lib().pto_trace_samples(C.byref(desc), C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), n, xy.ctypes.data, base.ctypes.data,
+                            rng.ctypes.data, int(libm), out.ctypes.data, nthreads)
+    return out[:, :3].copy(), out[:, 3].copy().view(np.uint32)
+
+
+def texture_parameters(sd, params, tri, u, v):
+    desc, keep = make_scene_desc(sd)
+    tri, u, v = np.ascontiguousarray(tri, np.int32), _f32(u), _f32(v)
+    out = np.empty((tri.shape[0], 9), np.float32)
+    lib().pto_texture_parameters(C.byref(desc), C.byref(params), tri.shape[0], tri.ctypes.data, u.ctypes.data, v.ctypes.data, out.ctypes.data)
+    return out[:, 0:3].copy(), out[:, 3:6].copy(), out[:, 6:9].copy()
+
+
+def light_to_sample(lights, pos, rng_state):
+    pos, rng = _f32(pos).reshape(-1, 3), np.ascontiguousarray(rng_state, np.uint32).reshape(-1, 2)
+    out = np.empty((pos.shape[0], 2), np.int32)
+    larr = (Light * len(lights))(*lights)
+    lib().pto_light_to_sample(C.cast(larr, _P), len(lights), pos.shape[0], pos.ctypes.data, rng.ctypes.data, out.ctypes.data)
+    return out[:, 0].copy(), out[:, 1].copy()
 
 
 def resolve(accum, libm=False):

@@ -96,6 +96,10 @@ SIGNATURES = [
     ("ptgpu_gen_shadow_dev", C.c_int, [_P, C.POINTER(Light), C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("ptgpu_render_pass_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("ptgpu_render_pass", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("ptgpu_trace_samples_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    ("ptgpu_trace_samples", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    ("ptgpu_texture_parameters_batch", C.c_int, [_P, C.POINTER(Params), C.c_int64, _P, _P, _P, _P]),
+    ("ptgpu_light_to_sample_batch", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     ("ptgpu_resolve_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     ("ptgpu_spill_status", C.c_int, [_P, C.POINTER(C.c_uint64 * 3)]),
     ("ptgpu_comm_create_id", C.c_int, [_P]),
@@ -233,6 +237,15 @@ class Context:
     def tiles_unpack_dev(self, width, height, world, rank, d_slices, d_accum):
         _check(self.lib.ptgpu_tiles_unpack_dev(self.handle, width, height, world, rank, d_slices, d_accum))
 
+    def light_to_sample(self, lights, pos, rng_state):
+        """getLightToSample for n positions -> (light index [n], stream counter after the call [n])."""
+        pos, rng = _f32(pos).reshape(-1, 3), np.ascontiguousarray(rng_state, np.uint32).reshape(-1, 2)
+        out = np.empty((pos.shape[0], 2), np.int32)
+        larr = (Light * len(lights))(*lights)
+        _check(self.lib.ptgpu_light_to_sample_batch(self.handle, C.cast(larr, _P), len(lights), pos.shape[0], pos.ctypes.data, rng.ctypes.data,
+                                                    out.ctypes.data))
+        return out[:, 0].copy(), out[:, 1].copy()
+
     def resolve_dev(self, d_accum, width, height, d_out):
         _check(self.lib.ptgpu_resolve_dev(self.handle, d_accum, width, height, d_out))
 
@@ -336,6 +349,25 @@ class Scene:
 
     def gen_shadow_dev(self, light, n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid):
         _check(self.lib.ptgpu_gen_shadow_dev(self.handle, C.byref(light), n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid))
+
+    def trace_samples(self, params, cam, lights, xy, sampler_base, rng_state):
+        """tracePath / traceWhitted for n arbitrary samples -> (radiance [n,3] float32, stream counters after the call [n] uint32)."""
+        xy, base = _f32(xy).reshape(-1, 2), np.ascontiguousarray(sampler_base, np.int32)
+        rng = np.ascontiguousarray(rng_state, np.uint32).reshape(-1, 2)
+        n = xy.shape[0]
+        out = np.empty((n, 4), np.float32)
+        larr = (Light * len(lights))(*lights)
+        _check(self.lib.ptgpu_trace_samples(self.handle, C.byref(params), C.byref(cam), C.cast(larr, _P), len(lights), n, xy.ctypes.data,
+                                            base.ctypes.data, rng.ctypes.data, out.ctypes.data))
+        return out[:, :3].copy(), out[:, 3].copy().view(np.uint32)
+
+    def texture_parameters(self, params, tri, u, v):
+        """getTextureParameters for n hits -> (diffuse [n,3], normal [n,3], specular [n,3])."""
+        tri, u, v = np.ascontiguousarray(tri, np.int32), _f32(u), _f32(v)
+        out = np.empty((tri.shape[0], 9), np.float32)
+        _check(self.lib.ptgpu_texture_parameters_batch(self.handle, C.byref(params), tri.shape[0], tri.ctypes.data, u.ctypes.data, v.ctypes.data,
+                                                       out.ctypes.data))
+        return out[:, 0:3].copy(), out[:, 3:6].copy(), out[:, 6:9].copy()
 
     def render_pass(self, params, cam, lights, accum=None, block_begin=0, block_end=-1, block_stride=1):
         """One pathTraceBlock pass over the selected blocks, accumulated into (a copy of) accum [h,w,4] on the host."""

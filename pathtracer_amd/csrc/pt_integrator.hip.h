@@ -39,6 +39,13 @@ struct PassDesc {
     int32_t samples_per_block; // padded: 1024 * num_aa_rays
     int32_t num_lights;
     float inv_prob;            // 1 / m_terminationProbability (:468)
+    // EXT instantiation only (ptgpu_trace_samples_dev): the launch traces num_ext caller-given samples instead of blocks -- sample s
+    // has clip-space position ext_xy[2s..], Sobol base ext_base[s] and random stream state (key, counter) ext_rng[2s..]; exactly the
+    // arguments of the reference's tracePath(x, y, ctx, samplerBase, R, ...) (src/PathTraceRenderer.hpp:97-98)
+    const float* ext_xy;
+    const int32_t* ext_base;
+    const uint32_t* ext_rng;
+    uint32_t num_ext;
 };
 
 // x / 255.0f for x = 0, 1, ..., 255: one multiply and two fused steps give the correctly rounded quotient for every one of the 256
@@ -310,7 +317,7 @@ struct PathState {
 
 // One integrator launch.  rad[sid] = (Ei.rgb, aux) for every valid padded sample id of the launch's blocks.
 // spill: samples of Sobol-block mode whose pixel falls outside their own block (sobol() == 1.0f exactly, p = 2^-24).
-template <bool COUNT, int NLDS, bool OVF, int BLOCK, bool ALPHA>
+template <bool COUNT, int NLDS, bool OVF, int BLOCK, bool ALPHA, bool EXT = false>
 __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene& SS, const ptgpu_params& prm, const ptgpu_camera& cam,
                                           const ptgpu_light* __restrict__ lights, const PassDesc& pd, float4* __restrict__ rad,
                                           unsigned long long* counters, uint2* lds_lane, uint2* gl_lane, int service_threshold_packed) {
@@ -327,7 +334,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
 
     // Sample ids of one launch fit 31 bits (the host caps a batch at 2^30).  The chunk cursor is wave-uniform: readfirstlane keeps it in
     // scalar registers (as 64-bit per-lane values it cost 8 VGPRs for the whole life of the kernel).
-    const uint32_t total = (uint32_t)pd.num_blocks * (uint32_t)pd.samples_per_block;
+    const uint32_t total = EXT ? pd.num_ext : (uint32_t)pd.num_blocks * (uint32_t)pd.samples_per_block;
     const uint32_t total_waves = gridDim.x * (BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     uint32_t next = 0, end = 0, round = 0xffffffffu;
@@ -338,7 +345,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
     // finish a sample: its radiance leaves through rad[], the lane becomes idle
     auto finish = [&]() {
         float4 o;
-        o.x = ps.Ei.x; o.y = ps.Ei.y; o.z = ps.Ei.z; o.w = ps.aux;
+        o.x = ps.Ei.x; o.y = ps.Ei.y; o.z = ps.Ei.z; o.w = EXT ? __uint_as_float(ps.R.ctr) : ps.aux;  // EXT: where the sample left its random stream
         rad[ps.sid] = o;
         ps.stage = ST_IDLE;
         ps.sid = -1;
@@ -594,6 +601,16 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         asm volatile("" : "+s"(n_width), "+s"(n_height), "+s"(n_spb), "+s"(n_blocks_x), "+s"(n_aa), "+s"(n_filter));
                         const float div_x = 1.0f / (float)n_width, div_y = 1.0f / (float)n_height;
                         const int sid = (int)(next + (uint32_t)rank);
+                        bool valid;
+                        float px = 0.0f, py = 0.0f, ext_x = 0.0f, ext_y = 0.0f;
+                        int sbase;
+                        if (EXT) {  // caller-given sample: tracePath's own arguments
+                            valid = true;
+                            ext_x = pd.ext_xy[2 * (size_t)sid]; ext_y = pd.ext_xy[2 * (size_t)sid + 1];
+                            sbase = pd.ext_base[sid];
+                            ps.R.key = pd.ext_rng[2 * (size_t)sid]; ps.R.ctr = pd.ext_rng[2 * (size_t)sid + 1];
+                            ps.aux = 0.0f;
+                        } else {
                         const int jj = (int)((uint32_t)sid / (uint32_t)n_spb);
                         const int s = sid - jj * n_spb;
                         const int idx = pd.block_begin + (pd.j0 + jj) * pd.block_stride;
@@ -601,9 +618,6 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         const int bw = (bx + 32 < n_width) ? 32 : n_width - bx;
                         const int bh = (by + 32 < n_height) ? 32 : n_height - by;
                         const int base = block_sobol_base(idx, prm.pass_seed);
-                        bool valid;
-                        float px, py;
-                        int sbase;
                         if (prm.sobol_block) {  // reference :706-727
                             const int i = s;
                             valid = i < bw * bh * n_aa;
@@ -635,9 +649,10 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                             const float fs = 2.0f / n_filter;
                             ps.aux = gauss(fs * (a - 0.5f), fs * (b - 0.5f));
                         }
+                        }
                         if (valid) {
-                            float x = px * div_x * 2.0f - 1.0f;
-                            float y = py * div_y * -2.0f + 1.0f;
+                            float x = EXT ? ext_x : px * div_x * 2.0f - 1.0f;
+                            float y = EXT ? ext_y : py * div_y * -2.0f + 1.0f;
                             // camera ray, reference :244-292
                             F4 Roh = mul44(cam.invP, x, y, 0.0f, 1.0f);
                             float iw0 = 1.0f / Roh.w;

@@ -822,7 +822,7 @@ constexpr int PT_BLOCK = PT_BLOCK_THREADS;
                         // Measured on the configs[2] frame: 4 waves + 16 LDS stack entries 32.0 ms vs 3 waves + 24 entries 34.6 ms per 16 spp
 #endif
 
-template <bool COUNT, int NLDS, bool OVF, bool ALPHA>
+template <bool COUNT, int NLDS, bool OVF, bool ALPHA, bool EXT = false>
 #ifdef PT_WAVES_PER_EU
 // Diagnostic build: force the register allocator to a given occupancy.  5 waves/SIMD = 96 VGPRs + 236 B of scratch per lane: 27.3 ms per
 // 16 spp pass against 25.3 ms for the 4-wave / 128-VGPR build below (whose run time scales almost linearly with waves: 2 / 3 / 4 waves
@@ -838,7 +838,7 @@ ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
     __shared__ uint2 lds_stack[PT_BLOCK / 64][NLDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t wave_id = (size_t)blockIdx.x * (PT_BLOCK / 64) + wave;
-    ptd::integrate<COUNT, NLDS, OVF, PT_BLOCK, ALPHA>(TS, SS, prm, cam, lights, pd, rad, counters, &lds_stack[wave][0][lane],
+    ptd::integrate<COUNT, NLDS, OVF, PT_BLOCK, ALPHA, EXT>(TS, SS, prm, cam, lights, pd, rad, counters, &lds_stack[wave][0][lane],
                                                OVF ? stack_ovf + wave_id * (64 - NLDS) * 64 + lane : nullptr, service_threshold);
 }
 
@@ -1004,27 +1004,40 @@ static int check_params(const ptgpu_params* p) {
     return PTGPU_OK;
 }
 
-template <bool COUNT, int NLDS, bool OVF, bool ALPHA>
+// light table of the context: re-uploaded only when it changed (synchronous, rare)
+static int upload_lights(ptgpu_context* c, const ptgpu_light* lights, int32_t num_lights) {
+    if ((int)c->h_lights.size() == num_lights && memcmp(c->h_lights.data(), lights, sizeof(ptgpu_light) * num_lights) == 0) return PTGPU_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_lights) { HIP_TRY(hipFree(c->d_lights)); c->d_lights = nullptr; }
+    c->h_lights.clear();
+    HIP_TRY(hipMalloc(&c->d_lights, sizeof(ptgpu_light) * num_lights));
+    HIP_TRY(hipMemcpy(c->d_lights, lights, sizeof(ptgpu_light) * num_lights, hipMemcpyHostToDevice));
+    c->h_lights.assign(lights, lights + num_lights);
+    return PTGPU_OK;
+}
+
+template <bool COUNT, int NLDS, bool OVF, bool ALPHA, bool EXT = false>
 static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const ptd::ShadeScene& ss, const ptgpu_params* prm, const ptgpu_camera* cam,
-                            const ptd::PassDesc& pd) {
+                            const ptd::PassDesc& pd, float4* rad = nullptr) {
     ptgpu_context* c = s->ctx;
     static std::atomic<int> per_cu_cache{0};  // same value whichever thread computes it first
     int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_integrate<COUNT, NLDS, OVF, ALPHA>, PT_BLOCK, 0) != hipSuccess || v < 1) v = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_integrate<COUNT, NLDS, OVF, ALPHA, EXT>, PT_BLOCK, 0) != hipSuccess || v < 1) v = 1;
         per_cu = v;
         per_cu_cache.store(v, std::memory_order_relaxed);
     }
-    const long long total = (long long)pd.num_blocks * pd.samples_per_block;
+    const long long total = EXT ? (long long)pd.num_ext : (long long)pd.num_blocks * pd.samples_per_block;
     long long blocks = (total + PT_BLOCK - 1) / PT_BLOCK;
+    if (blocks < 1) blocks = 1;
     const long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_PT_OVERSUB", 4);
     if (blocks > resident) blocks = resident;
     if (OVF) {
         int rc = ensure_stack_overflow(c, (size_t)blocks * (PT_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
         if (rc != PTGPU_OK) return rc;
     }
-    hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF, ALPHA>), dim3((unsigned)blocks), dim3(PT_BLOCK), (size_t)env_int("PTGPU_PT_EXTRA_LDS", 0), c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
+    hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF, ALPHA, EXT>), dim3((unsigned)blocks), dim3(PT_BLOCK), (size_t)env_int("PTGPU_PT_EXTRA_LDS", 0), c->stream, trav, ss, *prm, *cam, c->d_lights, pd, rad ? rad : c->d_rad,
                        c->d_counters, env_int("PTGPU_PT_SERVICE", 32) | (env_int("PTGPU_PT_CTLMIN", 16) << 8), c->d_stack_ovf);
     return PTGPU_OK;
 }
@@ -1042,14 +1055,8 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     if (block_begin >= block_end) return PTGPU_OK;
     ptgpu_context* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    // light table: re-uploaded only when it changed (synchronous, rare)
-    if ((int)c->h_lights.size() != num_lights || memcmp(c->h_lights.data(), lights, sizeof(ptgpu_light) * num_lights) != 0) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->d_lights) { HIP_TRY(hipFree(c->d_lights)); c->d_lights = nullptr; }
-        HIP_TRY(hipMalloc(&c->d_lights, sizeof(ptgpu_light) * num_lights));
-        HIP_TRY(hipMemcpy(c->d_lights, lights, sizeof(ptgpu_light) * num_lights, hipMemcpyHostToDevice));
-        c->h_lights.assign(lights, lights + num_lights);
-    }
+    rc = upload_lights(c, lights, num_lights);
+    if (rc != PTGPU_OK) return rc;
     rc = ptgpu_ensure_spill_lists(c);
     if (rc != PTGPU_OK) return rc;
     // spill list and dropped-sample count are per pass (all batches of this call append to one list, applied after the last block sum)
@@ -1083,6 +1090,7 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
         pd.num_blocks = (count - j0 < batch_blocks) ? count - j0 : (int)batch_blocks;
         pd.blocks_x = blocks_x; pd.samples_per_block = (int32_t)spb; pd.num_lights = num_lights;
         pd.inv_prob = 1.0f / prm->termination_prob;
+        pd.ext_xy = nullptr; pd.ext_base = nullptr; pd.ext_rng = nullptr; pd.num_ext = 0;
         // the alpha-cutout code is only compiled into the variants a scene with alpha maps takes (fewer registers for all others)
 #define PT_LAUNCH(COUNT_, NLDS_, OVF_) (trav.alpha_on ? launch_integrate<COUNT_, NLDS_, OVF_, true>(s, trav, ss, prm, cam, pd) \
                                                       : launch_integrate<COUNT_, NLDS_, OVF_, false>(s, trav, ss, prm, cam, pd))
@@ -1143,6 +1151,139 @@ extern "C" int ptgpu_render_pass(ptgpu_scene* s, const ptgpu_params* prm, const 
     unsigned long long ovf = 0;
     HIP_TRY(hipMemcpy(&ovf, c->d_counters + CTR_DROPPED, sizeof ovf, hipMemcpyDeviceToHost));
     if (ovf) return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples of this pass did not fit the spill lists and were dropped", ovf);
+    return PTGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-sample entry points: the reference's static PathTraceRenderer functions (src/PathTraceRenderer.hpp:97-102) for arbitrary
+// arguments, traced / evaluated by the SAME device code the render pass runs (ptd::integrate, get_texture_parameters,
+// get_light_to_sample) -- so tracePath is checked sample by sample, not only through pixel sums.
+// ------------------------------------------------------------------------------------------------
+extern "C" int ptgpu_trace_samples_dev(ptgpu_scene* s, const ptgpu_params* prm, const ptgpu_camera* cam, const ptgpu_light* lights, int32_t num_lights,
+                                       int64_t n, const float* d_xy, const int32_t* d_sampler_base, const uint32_t* d_rng_state, float* d_out) {
+    if (!s || !prm || !cam || !lights) return fail(PTGPU_E_INVALID, "NULL argument");
+    int rc = check_params(prm);
+    if (rc != PTGPU_OK) return rc;
+    if (num_lights < 1 || num_lights > 1024) return fail(PTGPU_E_INVALID, "num_lights %d out of range [1,1024]", num_lights);
+    if (n < 0 || n > (1LL << 30)) return fail(PTGPU_E_INVALID, "n = %lld out of range [0, 2^30]", (long long)n);
+    if (n == 0) return PTGPU_OK;
+    if (!d_xy || !d_sampler_base || !d_rng_state || !d_out) return fail(PTGPU_E_INVALID, "NULL device array");
+    ptgpu_context* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = upload_lights(c, lights, num_lights);
+    if (rc != PTGPU_OK) return rc;
+    ptd::TravScene trav = s->trav;
+    trav.alpha_on = (prm->use_alpha && s->has_alpha) ? 1 : 0;
+    ptd::ShadeScene ss;
+    ss.pos = s->d_pos; ss.nrm = s->d_nrm; ss.uv = s->d_uv; ss.materials = s->d_materials; ss.textures = s->d_textures;
+    ss.sobol_pairs = c->d_sobol_pairs;
+    ptd::PassDesc pd{};
+    pd.block_stride = 1; pd.blocks_x = (prm->width + 31) / 32; pd.samples_per_block = 1024 * prm->num_aa_rays; pd.num_lights = num_lights;
+    pd.inv_prob = 1.0f / prm->termination_prob;
+    pd.ext_xy = d_xy; pd.ext_base = d_sampler_base; pd.ext_rng = d_rng_state; pd.num_ext = (uint32_t)n;
+    // one configuration that is valid for every tree depth (16 LDS stack entries + global overflow)
+    rc = trav.alpha_on ? launch_integrate<false, 16, true, true, true>(s, trav, ss, prm, cam, pd, reinterpret_cast<float4*>(d_out))
+                       : launch_integrate<false, 16, true, false, true>(s, trav, ss, prm, cam, pd, reinterpret_cast<float4*>(d_out));
+    if (rc != PTGPU_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_trace_samples(ptgpu_scene* s, const ptgpu_params* prm, const ptgpu_camera* cam, const ptgpu_light* lights, int32_t num_lights,
+                                   int64_t n, const float* xy, const int32_t* sampler_base, const uint32_t* rng_state, float* out) {
+    if (!s) return fail(PTGPU_E_INVALID, "scene is NULL");
+    if (n < 0 || n > (1LL << 30)) return fail(PTGPU_E_INVALID, "n = %lld out of range [0, 2^30]", (long long)n);
+    if (n == 0) return PTGPU_OK;
+    if (!xy || !sampler_base || !rng_state || !out) return fail(PTGPU_E_INVALID, "NULL array");
+    ptgpu_context* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)n, b8 = (N * 8 + 255) & ~(size_t)255, b4 = (N * 4 + 255) & ~(size_t)255;
+    int rc = ensure_stage(c, 2 * b8 + b4 + N * 16);
+    if (rc != PTGPU_OK) return rc;
+    unsigned char* b = c->d_stage;
+    float* d_xy = (float*)b;
+    uint32_t* d_rng = (uint32_t*)(b + b8);
+    int32_t* d_base = (int32_t*)(b + 2 * b8);
+    float* d_out = (float*)(b + 2 * b8 + b4);
+    HIP_TRY(hipMemcpyAsync(d_xy, xy, N * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_rng, rng_state, N * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_base, sampler_base, N * 4, hipMemcpyHostToDevice, c->stream));
+    rc = ptgpu_trace_samples_dev(s, prm, cam, lights, num_lights, n, d_xy, d_base, d_rng, d_out);
+    if (rc != PTGPU_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out, d_out, N * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
+}
+
+// getTextureParameters (reference src/PathTraceRenderer.cpp:75-181) for n hits (triangle, u, v)
+__global__ void k_texture_parameters(ptd::ShadeScene SS, ptgpu_params prm, const int32_t* __restrict__ mat_id, int num_tris, long long n,
+                                     const int32_t* __restrict__ tri, const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ out9) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tri[i];
+    ptd::F3 diffuse = ptd::f3(0, 0, 0), nrm = diffuse, specular = diffuse;
+    if (t >= 0 && t < num_tris) ptd::get_texture_parameters(SS, prm, t, mat_id[t], u[i], v[i], diffuse, nrm, specular);
+    float* o = out9 + i * 9;
+    o[0] = diffuse.x; o[1] = diffuse.y; o[2] = diffuse.z; o[3] = nrm.x; o[4] = nrm.y; o[5] = nrm.z; o[6] = specular.x; o[7] = specular.y; o[8] = specular.z;
+}
+
+// getLightToSample (reference src/PathTraceRenderer.cpp:183-210) for n positions, each with its own random-stream state
+__global__ void k_light_to_sample(const ptgpu_light* __restrict__ lights, int num_lights, long long n, const float* __restrict__ pos,
+                                  const uint32_t* __restrict__ rng_state, int32_t* __restrict__ out2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ptd::Rng R;
+    R.key = rng_state[2 * i]; R.ctr = rng_state[2 * i + 1];
+    out2[2 * i] = ptd::get_light_to_sample(ptd::ld3(pos + 3 * i), lights, num_lights, R);
+    out2[2 * i + 1] = (int32_t)R.ctr;
+}
+
+extern "C" int ptgpu_texture_parameters_batch(ptgpu_scene* s, const ptgpu_params* prm, int64_t n, const int32_t* tri, const float* u, const float* v,
+                                              float* out_diffuse_normal_specular) {
+    if (!s || !prm) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (n < 0 || n > (1LL << 28)) return fail(PTGPU_E_INVALID, "n = %lld out of range", (long long)n);
+    if (n == 0) return PTGPU_OK;
+    if (!tri || !u || !v || !out_diffuse_normal_specular) return fail(PTGPU_E_INVALID, "NULL array");
+    ptgpu_context* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)n, b4 = (N * 4 + 255) & ~(size_t)255;
+    int rc = ensure_stage(c, 3 * b4 + N * 36);
+    if (rc != PTGPU_OK) return rc;
+    unsigned char* b = c->d_stage;
+    HIP_TRY(hipMemcpyAsync(b, tri, N * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(b + b4, u, N * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(b + 2 * b4, v, N * 4, hipMemcpyHostToDevice, c->stream));
+    ptd::ShadeScene ss;
+    ss.pos = s->d_pos; ss.nrm = s->d_nrm; ss.uv = s->d_uv; ss.materials = s->d_materials; ss.textures = s->d_textures; ss.sobol_pairs = c->d_sobol_pairs;
+    hipLaunchKernelGGL(k_texture_parameters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ss, *prm, s->d_mat_id, s->num_tris, (long long)n,
+                       (const int32_t*)b, (const float*)(b + b4), (const float*)(b + 2 * b4), (float*)(b + 3 * b4));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_diffuse_normal_specular, b + 3 * b4, N * 36, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_light_to_sample_batch(ptgpu_context* c, const ptgpu_light* lights, int32_t num_lights, int64_t n, const float* pos,
+                                           const uint32_t* rng_state, int32_t* out_index_and_counter) {
+    if (!c || !lights) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (num_lights < 1 || num_lights > 1024) return fail(PTGPU_E_INVALID, "num_lights %d out of range [1,1024]", num_lights);
+    if (n < 0 || n > (1LL << 28)) return fail(PTGPU_E_INVALID, "n = %lld out of range", (long long)n);
+    if (n == 0) return PTGPU_OK;
+    if (!pos || !rng_state || !out_index_and_counter) return fail(PTGPU_E_INVALID, "NULL array");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_lights(c, lights, num_lights);
+    if (rc != PTGPU_OK) return rc;
+    const size_t N = (size_t)n, b12 = (N * 12 + 255) & ~(size_t)255, b8 = (N * 8 + 255) & ~(size_t)255;
+    rc = ensure_stage(c, b12 + 2 * b8);
+    if (rc != PTGPU_OK) return rc;
+    unsigned char* b = c->d_stage;
+    HIP_TRY(hipMemcpyAsync(b, pos, N * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(b + b12, rng_state, N * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_light_to_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_lights, (int)num_lights, (long long)n,
+                       (const float*)b, (const uint32_t*)(b + b12), (int32_t*)(b + b12 + b8));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_index_and_counter, b + b12 + b8, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return PTGPU_OK;
 }
 

@@ -42,19 +42,109 @@ ptgpu_camera makeCameraPod(const CameraControls& cam, int width, int height) {
     return out;
 }
 
-ptgpu_params PathTraceRenderer::currentParams() const {
+RayTracer* PathTraceRenderer::s_rt = nullptr;
+
+ptgpu_params PathTraceRenderer::paramsOf(const PathTracerContext& ctx) {
     ptgpu_params p{};
-    Vec2i size = m_context.m_destImage ? m_context.m_destImage->getSize() : Vec2i(0, 0);
+    Vec2i size = ctx.m_destImage ? ctx.m_destImage->getSize() : Vec2i(0, 0);
     p.width = size.x; p.height = size.y;
-    p.bounces = m_context.m_bounces;
+    p.bounces = ctx.m_bounces;
     p.num_aa_rays = m_NumAaRays;
     p.sobol_block = m_sobolBlock; p.bilinear = m_bilinearFiltering; p.normal_mapped = m_normalMapped;
     p.depth_of_field = m_depthOfField; p.whitted = m_whitted; p.num_light_rays = m_numLightRays;
-    p.use_alpha = (m_context.m_rt && m_context.m_rt->useAlpha) ? 1 : 0;
-    p.pass_seed = m_passSeed;
+    p.use_alpha = (ctx.m_rt && ctx.m_rt->useAlpha) ? 1 : 0;
+    p.pass_seed = ctx.m_passSeed;
     p.aperture = m_aperture; p.attenuation = m_attenuation; p.filter_width = m_filterWidth;
     p.focal_distance = m_focalDistance; p.intensity = m_intensity; p.termination_prob = m_terminationProbability;
     return p;
+}
+ptgpu_params PathTraceRenderer::currentParams() const { return paramsOf(m_context); }
+
+namespace {
+std::vector<ptgpu_light> lightPods(const std::vector<AreaLight>* lights) {
+    std::vector<ptgpu_light> pods;
+    if (lights) for (const AreaLight& l : *lights) pods.push_back(l.toPod());
+    return pods;
+}
+void requireContext(const PathTracerContext& ctx, const char* who) {
+    if (!ctx.m_rt || !ctx.m_camera || !ctx.m_destImage || !ctx.m_lights || ctx.m_lights->empty())
+        throw GpuError(std::string(who) + ": the context needs a tracer, camera, destination image and at least one light");
+}
+}  // namespace
+
+void PathTraceRenderer::prepareContext(std::vector<AreaLight>* lights, RayTracer* rt, Image* dest, int bounces, const CameraControls& camera) {
+    m_context.m_camera = &camera;
+    m_context.m_rt = rt;
+    m_context.m_lights = lights;
+    m_context.m_light = (lights && !lights->empty()) ? &(*lights)[0] : nullptr;
+    m_context.m_bounces = bounces;
+    m_context.m_destImage = dest;
+    if (dest && (!m_context.m_image || !(m_context.m_image->getSize() == dest->getSize())))
+        m_context.m_image.reset(new Image(dest->getSize(), ImageFormat::RGBA_Vec4f));
+    s_rt = rt;
+}
+
+// tracePath / traceWhitted: one sample through ptgpu_trace_samples (reference :236-551 / :553-660)
+Vec3f PathTraceRenderer::traceOne(float x, float y, PathTracerContext& ctx, int samplerBase, Random& rnd, bool whitted) {
+    requireContext(ctx, whitted ? "traceWhitted" : "tracePath");
+    ptgpu_params p = paramsOf(ctx);
+    p.whitted = whitted ? 1 : 0;
+    const Vec2i size = ctx.m_destImage->getSize();
+    const ptgpu_camera cam = makeCameraPod(*ctx.m_camera, size.x, size.y);
+    const std::vector<ptgpu_light> pods = lightPods(ctx.m_lights);
+    const float xy[2] = {x, y};
+    const int32_t base = samplerBase;
+    const uint32_t state[2] = {rnd.key(), rnd.counter()};
+    float out[4];
+    PT_GPU(ptgpu_trace_samples(ctx.m_rt->deviceScene(), &p, &cam, pods.data(), (int32_t)pods.size(), 1, xy, &base, state, out));
+    uint32_t ctr;
+    std::memcpy(&ctr, &out[3], 4);
+    rnd.setCounter(ctr);
+    return Vec3f(out[0], out[1], out[2]);
+}
+Vec3f PathTraceRenderer::tracePath(float x, float y, PathTracerContext& ctx, int samplerBase, Random& rnd, std::vector<PathVisualizationNode>&) {
+    return traceOne(x, y, ctx, samplerBase, rnd, false);
+}
+Vec3f PathTraceRenderer::traceWhitted(float x, float y, PathTracerContext& ctx, int samplerBase, Random& rnd, std::vector<PathVisualizationNode>&) {
+    return traceOne(x, y, ctx, samplerBase, rnd, true);
+}
+
+// reference :183-210
+int PathTraceRenderer::getLightToSample(const Vec3f pos, const std::vector<AreaLight>* lights, Random& R) {
+    const std::vector<ptgpu_light> pods = lightPods(lights);
+    if (pods.empty()) throw GpuError("getLightToSample: no lights");
+    const uint32_t state[2] = {R.key(), R.counter()};
+    int32_t out[2];
+    PT_GPU(ptgpu_light_to_sample_batch(GpuDevice::instance().ctx(), pods.data(), (int32_t)pods.size(), 1, &pos.x, state, out));
+    R.setCounter((uint32_t)out[1]);
+    return out[0];
+}
+
+// reference :75-181
+void PathTraceRenderer::getTextureParameters(const RaycastResult& hit, Vec3f& diffuse, Vec3f& n, Vec3f& specular) {
+    if (!s_rt || !s_rt->m_triangles || !hit.tri) throw GpuError("getTextureParameters: no active tracer or no hit");
+    const std::vector<RTTriangle>& T = *s_rt->m_triangles;
+    const ptrdiff_t idx = hit.tri - T.data();
+    if (idx < 0 || (size_t)idx >= T.size()) throw GpuError("getTextureParameters: the hit's triangle does not belong to the active tracer");
+    ptgpu_params p{};
+    p.width = p.height = 1; p.num_aa_rays = 1; p.num_light_rays = 1; p.filter_width = 1.0f; p.termination_prob = 1.0f;
+    p.bilinear = m_bilinearFiltering; p.normal_mapped = m_normalMapped;
+    const int32_t tri = (int32_t)idx;
+    float out[9];
+    PT_GPU(ptgpu_texture_parameters_batch(s_rt->deviceScene(), &p, 1, &tri, &hit.u, &hit.v, out));
+    diffuse = Vec3f(out[0], out[1], out[2]); n = Vec3f(out[3], out[4], out[5]); specular = Vec3f(out[6], out[7], out[8]);
+}
+
+// reference :663-790: one block, accumulated into the context's (host) accumulation image
+void PathTraceRenderer::pathTraceBlock(MulticoreLauncher::Task& t) {
+    PathTracerContext& ctx = *static_cast<PathTracerContext*>(t.data);
+    requireContext(ctx, "pathTraceBlock");
+    if (!ctx.m_image) throw GpuError("pathTraceBlock: the context has no accumulation image");
+    const ptgpu_params p = paramsOf(ctx);
+    const ptgpu_camera cam = makeCameraPod(*ctx.m_camera, p.width, p.height);
+    const std::vector<ptgpu_light> pods = lightPods(ctx.m_lights);
+    PT_GPU(ptgpu_render_pass(ctx.m_rt->deviceScene(), &p, &cam, pods.data(), (int32_t)pods.size(), t.idx, t.idx + 1, 1,
+                             (float*)ctx.m_image->getMutablePtr()));
 }
 
 void PathTraceRenderer::launchPass() {
@@ -62,7 +152,7 @@ void PathTraceRenderer::launchPass() {
     PT_GPU(ptgpu_render_pass_dev(m_context.m_rt->deviceScene(), &p, &m_cameraPod, m_lightPods.data(), (int32_t)m_lightPods.size(), m_blockBegin, -1,
                                  m_blockStride, m_accum.ptr()));
     if (m_gatherTiles) PT_GPU(ptgpu_gather_tiles_dev(GpuDevice::instance().ctx(), p.width, p.height, m_accum.ptr()));
-    ++m_passSeed;  // stands in for the reference's process-global seed counter (:689-691): every pass draws new samples
+    ++m_context.m_passSeed;  // stands in for the reference's process-global seed counter (:689-691): every pass draws new samples
     m_passInFlight = true;
 }
 
@@ -86,6 +176,7 @@ void PathTraceRenderer::startPathTracingProcess(const MeshWithColors* scene, std
     m_context.m_lights = lights;
     m_context.m_light = &(*lights)[0];
     m_context.m_pass = 0;
+    s_rt = rt;
     m_context.m_bounces = bounces;
     m_context.m_image.reset(new Image(dest->getSize(), ImageFormat::RGBA_Vec4f));
     m_context.m_destImage = dest;

@@ -23,6 +23,23 @@ struct PathTracerBlock {
     int m_x, m_y, m_width, m_height;
 };
 
+// Task handed to a worker by FW::MulticoreLauncher (absent from the reference's tree; the renderer's static pathTraceBlock keeps
+// its signature, reference src/PathTraceRenderer.hpp:102): data = PathTracerContext*, idx = block index.
+struct MulticoreLauncher {
+    struct Task {
+        void* data = nullptr;
+        int idx = 0;
+    };
+};
+
+// debug path visualisation records (reference src/PathTraceRenderer.hpp:56-79): GUI feature, kept so that tracePath's signature holds
+struct PathVisualizationLine { Vec3f start, stop, color; };
+struct PathVisualizationLabel { std::string text; Vec3f position; };
+struct PathVisualizationNode {
+    std::vector<PathVisualizationLabel> labels;
+    std::vector<PathVisualizationLine> lines;
+};
+
 struct PathTracerContext {
     AreaLight* m_light = nullptr;
     const CameraControls* m_camera = nullptr;
@@ -36,6 +53,7 @@ struct PathTracerContext {
     bool m_bResidual = false;
     int m_bounces = 0;
     int m_pass = 0;
+    uint32_t m_passSeed = 0;  // stands in for the reference's process-global seed counter (:689-691): advanced once per pass
     std::chrono::steady_clock::time_point start;
 };
 
@@ -55,6 +73,20 @@ public:
     // negative #bounces = -N: Russian roulette after N bounces; positive N: exactly N bounces
     void startPathTracingProcess(const MeshWithColors* scene, std::vector<AreaLight>* lights, RayTracer* rt, Image* dest, int bounces,
                                  const CameraControls& camera);
+    // The reference's static per-sample functions (src/PathTraceRenderer.hpp:97-102), same signatures.  Each is ONE call of the device
+    // code the render pass runs (ptgpu_trace_samples / ptgpu_light_to_sample_batch / ptgpu_texture_parameters_batch /
+    // ptgpu_render_pass over one block): a launch per call, meant for probing and tests, not for rendering.  R is advanced by the
+    // draws the sample consumed, as when the reference passes its Random by reference.  visualization is accepted and left empty.
+    static Vec3f tracePath(float x, float y, PathTracerContext& ctx, int samplerBase, Random& rnd, std::vector<PathVisualizationNode>& visualization);
+    static Vec3f traceWhitted(float x, float y, PathTracerContext& ctx, int samplerBase, Random& rnd, std::vector<PathVisualizationNode>& visualization);
+    static int getLightToSample(const Vec3f pos, const std::vector<AreaLight>* lights, Random& R);
+    // the hit's triangle must belong to the tracer of the last startPathTracingProcess / setActiveTracer call
+    static void getTextureParameters(const RaycastResult& hit, Vec3f& diffuse, Vec3f& n, Vec3f& specular);
+    static void pathTraceBlock(MulticoreLauncher::Task& t);  // accumulates block t.idx into ctx.m_image (host image)
+    static void setActiveTracer(RayTracer* rt) { s_rt = rt; }
+    // fills a context for the static functions without starting a render
+    void prepareContext(std::vector<AreaLight>* lights, RayTracer* rt, Image* dest, int bounces, const CameraControls& camera);
+
     void checkFinish(void);
     void stop(void);
     void updatePicture(Image* display);
@@ -94,6 +126,9 @@ public:
 
 protected:
     void launchPass();
+    static ptgpu_params paramsOf(const PathTracerContext& ctx);
+    static Vec3f traceOne(float x, float y, PathTracerContext& ctx, int samplerBase, Random& rnd, bool whitted);
+    static RayTracer* s_rt;
 
     float m_raysPerSecond = 0.0f;
     static bool m_bilinearFiltering;
@@ -115,7 +150,6 @@ protected:
     int m_blockBegin = 0, m_blockStride = 1, m_maxPasses = 0;
     bool m_gatherTiles = false;
     std::string m_outputDir;
-    uint32_t m_passSeed = 0;
     GpuBuffer<float> m_accum, m_resolved;
     ptgpu_camera m_cameraPod{};
     std::vector<ptgpu_light> m_lightPods;

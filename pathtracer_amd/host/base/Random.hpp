@@ -22,6 +22,7 @@ public:
     F32 getF32(F32 lo, F32 hi) { return getF32() * (hi - lo) + lo; }
     U32 key() const { return m_key; }
     U32 counter() const { return m_ctr; }
+    void setCounter(U32 c) { m_ctr = c; }  // the device hands back where a sample left the stream (ptgpu_trace_samples)
 
 private:
     static U32 mix(U32 x) {

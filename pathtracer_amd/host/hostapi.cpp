@@ -264,6 +264,84 @@ int pth_pt_render(void* h, const float eye[3], const float fwd[3], const float u
     });
 }
 
+// The static per-sample functions of PathTraceRenderer, called the way the reference calls them (one sample / hit / position / block per
+// call).  seeds [n][4]: Random(k0,k1,k2,k3) per sample; advance [n]: draws made on the stream before the call.
+// out_rgb [n][3], out_ctr [n]: tracePath / traceWhitted results and the stream counters afterwards.  light_out [n][2]: getLightToSample at
+// the sample's (x, y, 0.3) and the counter after it.  tex_out [n][9]: getTextureParameters of the primary hit of ray n (zero if it misses).
+// block_accum: pathTraceBlock(block_idx) into a zeroed context image [h][w][4] (may be NULL).
+int pth_pt_statics(void* h, const float eye[3], const float fwd[3], const float up[3], float fov, float nearD, float farD, int width, int height,
+                   const ptgpu_light* lights, int num_lights, const ptgpu_params* prm, int n, const float* xy, const int32_t* base,
+                   const uint32_t* seeds, const uint32_t* advance, float* out_rgb, uint32_t* out_ctr, int32_t* light_out, float* tex_out,
+                   int block_idx, float* block_accum) {
+    return guarded([&] {
+        TracerBox* b = static_cast<TracerBox*>(h);
+        CameraControls cam(Vec3f(eye[0], eye[1], eye[2]), Vec3f(fwd[0], fwd[1], fwd[2]), Vec3f(up[0], up[1], up[2]), fov, nearD, farD);
+        std::vector<AreaLight> ls;
+        for (int i = 0; i < num_lights; ++i) {
+            const ptgpu_light& p = lights[i];
+            AreaLight l(Vec3f(p.E[0], p.E[1], p.E[2]), Vec2f(p.size[0], p.size[1]), p.intensity);
+            Mat4f X;
+            std::memcpy(X.m, p.xform, 64);
+            l.setOrientation(X.getXYZ());
+            l.setPosition(X.getCol(3).getXYZ());
+            l.updatePower();
+            ls.push_back(l);
+        }
+        PathTraceRenderer r;
+        r.setAAmode(prm->sobol_block != 0); r.setAArays(prm->num_aa_rays); r.setAperture(prm->aperture); r.setAttenuation(prm->attenuation);
+        r.setBilinearFiltering(prm->bilinear != 0); r.setDOF(prm->depth_of_field != 0); r.setFilterWidth(prm->filter_width);
+        r.setFocalDistance(prm->focal_distance); r.setIntensity(prm->intensity); r.setLightRays(prm->num_light_rays);
+        r.setNormalMapped(prm->normal_mapped != 0); r.setTermination(prm->termination_prob); r.setWhitted(prm->whitted != 0);
+        b->rt.useAlpha = prm->use_alpha != 0;
+        Image dest(Vec2i(width, height), ImageFormat::RGBA_Vec4f);
+        r.prepareContext(&ls, &b->rt, &dest, prm->bounces, cam);
+        r.m_context.m_passSeed = prm->pass_seed;
+        std::vector<PathVisualizationNode> vis;
+        for (int i = 0; i < n; ++i) {
+            Random R(seeds[4 * i], seeds[4 * i + 1], seeds[4 * i + 2], seeds[4 * i + 3]);
+            R.setCounter(advance[i]);
+            Vec3f c = prm->whitted ? PathTraceRenderer::traceWhitted(xy[2 * i], xy[2 * i + 1], r.m_context, base[i], R, vis)
+                                   : PathTraceRenderer::tracePath(xy[2 * i], xy[2 * i + 1], r.m_context, base[i], R, vis);
+            std::memcpy(out_rgb + 3 * i, &c, 12);
+            out_ctr[i] = R.counter();
+            if (light_out) {
+                Random R2(seeds[4 * i], seeds[4 * i + 1], seeds[4 * i + 2], seeds[4 * i + 3]);
+                R2.setCounter(advance[i]);
+                light_out[2 * i] = PathTraceRenderer::getLightToSample(Vec3f(xy[2 * i], xy[2 * i + 1], 0.3f), &ls, R2);
+                light_out[2 * i + 1] = (int32_t)R2.counter();
+            }
+        }
+        if (block_accum) {
+            MulticoreLauncher::Task t;
+            t.data = &r.m_context;
+            t.idx = block_idx;
+            r.m_context.m_image->clear();
+            PathTraceRenderer::pathTraceBlock(t);
+            std::memcpy(block_accum, r.m_context.m_image->getPtr(), (size_t)width * height * 16);
+        }
+    });
+}
+// getTextureParameters(hit, ...) for the hits of n rays traced with RayTracer::raycastBatch; out [n][9], zero rows for misses
+int pth_pt_texture_parameters(void* h, int bilinear, int normal_mapped, const float* orig, const float* dir, int64_t n, float* out) {
+    return guarded([&] {
+        TracerBox* b = static_cast<TracerBox*>(h);
+        PathTraceRenderer r;
+        r.setBilinearFiltering(bilinear != 0);
+        r.setNormalMapped(normal_mapped != 0);
+        PathTraceRenderer::setActiveTracer(&b->rt);
+        std::vector<RaycastResult> res(n);
+        b->rt.raycastBatch(reinterpret_cast<const Vec3f*>(orig), reinterpret_cast<const Vec3f*>(dir), (size_t)n, false, res.data());
+        for (int64_t i = 0; i < n; ++i) {
+            float* o = out + i * 9;
+            std::memset(o, 0, 36);
+            if (!res[i].tri) continue;
+            Vec3f d, nn, sp;
+            PathTraceRenderer::getTextureParameters(res[i], d, nn, sp);
+            std::memcpy(o, &d, 12); std::memcpy(o + 3, &nn, 12); std::memcpy(o + 6, &sp, 12);
+        }
+    });
+}
+
 int pth_rt_ray_count(void* h) { return static_cast<TracerBox*>(h)->rt.getRayCount(); }
 void pth_rt_reset_ray_counter(void* h) { static_cast<TracerBox*>(h)->rt.resetRayCounter(); }
 

@@ -57,6 +57,9 @@ def lib():
         L.pth_rt_raycast.argtypes = [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P]
         L.pth_pt_render.argtypes = [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int, C.POINTER(Params), C.c_int,
                                     C.c_int, C.c_int, _P, _P, _P]
+        L.pth_pt_statics.argtypes = [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int, C.POINTER(Params), C.c_int,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]
+        L.pth_pt_texture_parameters.argtypes = [_P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]
         L.pth_rt_ray_count.argtypes = [_P]
         L.pth_rt_reset_ray_counter.argtypes = [_P]
         _lib = L
@@ -208,6 +211,30 @@ class HostRayTracer:
                    point=np.empty((n, 3), np.float32))
         _check(lib().pth_rt_raycast(self.h, o.ctypes.data, d.ctypes.data, n, int(occlusion), int(single), out["id"].ctypes.data,
                                     out["t"].ctypes.data, out["u"].ctypes.data, out["v"].ctypes.data, out["point"].ctypes.data))
+        return out
+
+    def statics(self, params, lights, xy, base, seeds, advance, block_idx=None, eye=(0.0, 0.0, 0.48), forward=(0.0, -0.1, -1.0), up=(0.0, 1.0, 0.0),
+                fov_deg=70.0, near=0.001, far=3.0):
+        """PathTraceRenderer::tracePath / traceWhitted (by params.whitted), getLightToSample and pathTraceBlock called as the reference calls
+        them, one sample per call.  Returns dict(rgb [n,3], ctr [n], light [n,2], block image or None)."""
+        xy, base = _f32(xy).reshape(-1, 2), np.ascontiguousarray(base, np.int32)
+        seeds, advance = np.ascontiguousarray(seeds, np.uint32).reshape(-1, 4), np.ascontiguousarray(advance, np.uint32)
+        n, w, h = xy.shape[0], params.width, params.height
+        rgb, ctr, light = np.empty((n, 3), np.float32), np.empty(n, np.uint32), np.empty((n, 2), np.int32)
+        blk = np.empty((h, w, 4), np.float32) if block_idx is not None else None
+        e, f, u = _f32(eye), _f32(forward), _f32(up)
+        larr = (Light * len(lights))(*lights)
+        _check(lib().pth_pt_statics(self.h, e.ctypes.data, f.ctypes.data, u.ctypes.data, fov_deg, near, far, w, h, C.cast(larr, _P), len(lights),
+                                    C.byref(params), n, xy.ctypes.data, base.ctypes.data, seeds.ctypes.data, advance.ctypes.data, rgb.ctypes.data,
+                                    ctr.ctypes.data, light.ctypes.data, None, -1 if block_idx is None else block_idx,
+                                    None if blk is None else blk.ctypes.data))
+        return dict(rgb=rgb, ctr=ctr, light=light, block=blk)
+
+    def texture_parameters_of_hits(self, orig, direction, bilinear=True, normal_mapped=True):
+        """PathTraceRenderer::getTextureParameters on the closest hits of n rays -> [n,9] (diffuse, normal, specular; zero rows = miss)."""
+        o, d = _f32(orig).reshape(-1, 3), _f32(direction).reshape(-1, 3)
+        out = np.empty((o.shape[0], 9), np.float32)
+        _check(lib().pth_pt_texture_parameters(self.h, int(bilinear), int(normal_mapped), o.ctypes.data, d.ctypes.data, o.shape[0], out.ctypes.data))
         return out
 
     def ray_count(self):

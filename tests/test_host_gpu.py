@@ -163,3 +163,41 @@ def test_ptrender_lbvh_builder_and_cache(tmp_path):
     _run_ptrender(tmp_path, "-builder", "lbvh", *args, "-o", "lbvh.png")
     c = hostapi.load_image(tmp_path / "lbvh.png")
     assert np.abs(a[..., :3].astype(np.int32) - c[..., :3].astype(np.int32)).mean() < 1.0
+
+
+def test_static_per_sample_functions_match_oracle(host_rt, head, oracle):
+    """PathTraceRenderer::tracePath / traceWhitted / getLightToSample / getTextureParameters / pathTraceBlock with the reference's static
+    signatures (src/PathTraceRenderer.hpp:97-102), one device call each: values and random draws consumed equal the oracle's."""
+    tex, index = scene.head_reference_textures(head["mesh"])
+    sd = dict(head["sd"])
+    sd["materials"], sd["textures"] = scene.mesh_materials(head["mesh"], textured=True, texture_index=index), tex
+    w, h, n = 96, 64, 150
+    rng = np.random.RandomState(31)
+    xy = rng.uniform(-0.9, 0.9, (n, 2)).astype(np.float32)
+    base = rng.randint(0, 1 << 20, n).astype(np.int32)
+    seeds = rng.randint(0, 1 << 31, (n, 4)).astype(np.uint32)
+    advance = rng.randint(0, 4, n).astype(np.uint32)
+    state = np.stack([np.array([oracle.rng_key(*k) for k in seeds], np.uint32), advance], 1)
+    cam = scene.make_camera(width=w, height=h)
+    lights = [scene.make_light(), scene.make_light(position=(0.4, 0.8, 0.5), size=(0.1, 0.2), E=(30, 40, 50))]
+    for whitted in (False, True):
+        prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=True, normal_mapped=True, whitted=whitted,
+                                num_light_rays=3, pass_seed=5)
+        got = host_rt.statics(prm, lights, xy, base, seeds, advance, block_idx=None if whitted else 4)
+        c_rgb, c_ctr = oracle.trace_samples(sd, prm, cam, lights, xy, base, state)
+        same = (got["rgb"].view(np.uint32) == c_rgb.view(np.uint32)) | (np.isnan(got["rgb"]) & np.isnan(c_rgb))
+        assert same.all() and np.array_equal(got["ctr"], c_ctr) and c_rgb.max() > 0.01
+        pos = np.concatenate([xy, np.full((n, 1), 0.3, np.float32)], 1)
+        ci, cc = oracle.light_to_sample(lights, pos, state)
+        assert np.array_equal(got["light"][:, 0], ci) and np.array_equal(got["light"][:, 1], cc) and len(np.unique(ci)) == 2
+        if not whitted:
+            c_img, _ = oracle.render_pass(sd, prm, cam, lights, nthreads=1, block_begin=4, block_end=5)
+            assert np.array_equal(got["block"].view(np.uint32), c_img.view(np.uint32)) and c_img[..., 3].sum() > 0
+    o, d = oracle.gen_primary(scene.make_camera(width=64, height=40), 64, 40)
+    hits = oracle.raycast(sd, o, d, False)
+    g9 = host_rt.texture_parameters_of_hits(o, d, bilinear=True, normal_mapped=True)
+    m = hits["id"] >= 0
+    cd, cn, cs = oracle.texture_parameters(sd, scene.make_params(bilinear=True, normal_mapped=True), hits["id"][m], hits["u"][m], hits["v"][m])
+    want = np.concatenate([cd, cn, cs], 1)
+    same = (g9[m].view(np.uint32) == want.view(np.uint32)) | (np.isnan(g9[m]) & np.isnan(want))
+    assert same.all() and m.sum() > 500 and not g9[~m].any()
