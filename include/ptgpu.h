@@ -187,6 +187,15 @@ int ptgpu_gen_shadow_dev(ptgpu_scene* scene, const ptgpu_light* light, int64_t n
                          const int32_t* d_id, const float* d_t, const float* d_u, const float* d_v,
                          float* d_sh_orig, float* d_sh_dir, int32_t* d_sh_valid);
 
+/* The BASELINE config 2 frame in ONE launch: for every pixel the primary ray of ptgpu_gen_primary_dev traced closest-hit
+ * (RayTracer::raycast(orig, dir, false), src/RayTracer.cpp:174-290) and, where it hits, the shadow ray of ptgpu_gen_shadow_dev traced
+ * any-hit (occlusion = true) -- the rays stay in registers instead of travelling through HBM between four launches.  DEVICE arrays
+ * [height*width] indexed by pixel: the primary hit record (d_id, d_t, d_u, d_v as ptgpu_raycast_batch_dev writes them; required) and
+ * the occluder the shadow ray found (d_shadow_id: -1 = none or no primary hit; NULL = primary rays only); bit-identical to the
+ * four-call sequence.  Alpha cutout is not applied.  Trees deeper than 25 levels: PTGPU_E_UNSUPPORTED (use the separate calls). */
+int ptgpu_trace_frame_dev(ptgpu_scene* scene, const ptgpu_camera* cam, const ptgpu_light* light, int32_t width, int32_t height, int32_t* d_id,
+                          float* d_t, float* d_u, float* d_v, int32_t* d_shadow_id);
+
 /* ---- PathTraceRenderer: replaces the worker-thread launch in startPathTracingProcess / checkFinish
  * (m_launcher.push(pathTraceBlock, ...), src/PathTraceRenderer.cpp:847-852, :906-910) and pathTraceBlock + tracePath
  * themselves (:663-790, :236-551).  One call = one pass over the 32x32 blocks (row-major block index as :816-841 numbers

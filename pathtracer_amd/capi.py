@@ -92,6 +92,7 @@ SIGNATURES = [
     ("ptgpu_raycast_batch", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
     ("ptgpu_raycast_batch_dev", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
     ("ptgpu_raycast_batch_dev_noalloc", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    ("ptgpu_trace_frame_dev", C.c_int, [_P, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     ("ptgpu_gen_primary_dev", C.c_int, [_P, C.POINTER(Camera), C.c_int32, C.c_int32, _P, _P]),
     ("ptgpu_gen_shadow_dev", C.c_int, [_P, C.POINTER(Light), C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("ptgpu_render_pass_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -346,6 +347,10 @@ class Scene:
     def raycast_dev_noalloc(self, d_orig, d_dir, n, occlusion, d_id, d_t, d_u, d_v, use_alpha=True):
         """The allocation-free variant (fixed scratch inside the library, n <= NOALLOC_MAX_RAYS)."""
         _check(self.lib.ptgpu_raycast_batch_dev_noalloc(self.handle, int(use_alpha), d_orig, d_dir, n, int(occlusion), d_id, d_t, d_u, d_v))
+
+    def trace_frame_dev(self, cam, light, width, height, d_id, d_t, d_u, d_v, d_shadow_id):
+        """Primary closest-hit + shadow any-hit rays of a whole frame in one launch (BASELINE configs[1])."""
+        _check(self.lib.ptgpu_trace_frame_dev(self.handle, C.byref(cam), C.byref(light), width, height, d_id, d_t, d_u, d_v, d_shadow_id))
 
     def gen_shadow_dev(self, light, n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid):
         _check(self.lib.ptgpu_gen_shadow_dev(self.handle, C.byref(light), n, d_orig, d_dir, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid))

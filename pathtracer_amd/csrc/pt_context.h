@@ -29,6 +29,10 @@ __attribute__((format(printf, 2, 3))) static inline int fail(int code, const cha
 //   [5] deferred rays of the raycast launch in flight      [6] entries pending in the foreign-spill list
 //   [8..28] diagnostic stamps (PT_STAMPS builds)
 constexpr int CTR_WORDS = 32;
+// Short kernels with one wave per workgroup count their rays per wave; tens of thousands of atomics on ONE word serialise (measured:
+// 32,400 same-address adds took 0.43 ms, three times the kernel), so those go to word CTR_WORDS + (workgroup & (RAY_SPREAD - 1)) and
+// ptgpu_get_counters folds the spread words into the ray count.
+constexpr int RAY_SPREAD = 1024;
 constexpr int CTR_SPILL = 3, CTR_DROPPED = 4, CTR_DEFER = 5, CTR_FOREIGN = 6;
 constexpr int SPILL_CAPACITY = 1 << 16;
 // Sobol-block samples whose pixel belongs to a block this process does not render (tile sharding): kept until the tiles are gathered.

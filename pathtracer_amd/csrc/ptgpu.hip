@@ -63,7 +63,11 @@ struct ptgpu_scene {
 
 // zero a few counter words with plain stores (the form measured to be visible to a later kernel's atomics on this stream)
 __global__ void k_zero_words(unsigned long long* p, int count) {
-    if ((int)threadIdx.x < count) p[threadIdx.x] = 0ull;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) p[i] = 0ull;
+}
+// the public counters (words 0..2) and the spread ray-count words
+__global__ void k_reset_counters(unsigned long long* p) {
+    for (int i = threadIdx.x; i < 3 + RAY_SPREAD; i += blockDim.x) p[i < 3 ? i : CTR_WORDS + (i - 3)] = 0ull;
 }
 
 // tab[(pair * 3 + k) * 256 + b] = XOR of the direction numbers of dimensions (2*pair, 2*pair + 1) selected by the bits of byte b at
@@ -86,8 +90,8 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c);
 static int init_context(ptgpu_context* c, const hipDeviceProp_t& prop) {
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIP_TRY(hipMalloc(&c->d_counters, CTR_WORDS * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_counters, 0, CTR_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->d_counters, (CTR_WORDS + RAY_SPREAD) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_counters, 0, (CTR_WORDS + RAY_SPREAD) * sizeof(unsigned long long)));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int entries = ptd::SOBOL_PAIRS * 3 * 256;
     HIP_TRY(hipMalloc(&c->d_sobol_pairs, (size_t)entries * sizeof(uint2)));
@@ -202,11 +206,13 @@ extern "C" int ptgpu_enable_counters(ptgpu_context* c, int on) {
 }
 extern "C" int ptgpu_get_counters(ptgpu_context* c, ptgpu_counters* out) {
     if (!c || !out) return fail(PTGPU_E_INVALID, "NULL argument");
-    unsigned long long h[3];
+    static_assert(CTR_WORDS >= 3, "public counters first");
+    std::vector<unsigned long long> h(CTR_WORDS + RAY_SPREAD);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), c->d_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out->rays = h[0]; out->node_visits = h[1]; out->tri_tests = h[2];
+    for (int i = 0; i < RAY_SPREAD; ++i) out->rays += h[CTR_WORDS + i];
     return PTGPU_OK;
 }
 #ifdef PT_STAMPS
@@ -222,7 +228,7 @@ extern "C" int ptgpu_debug_counters(ptgpu_context* c, unsigned long long* out32)
 extern "C" int ptgpu_reset_counters(ptgpu_context* c) {
     if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters, 3);  // spill / defer words are cleared per use
+    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(256), 0, c->stream, c->d_counters);  // spill / defer words are cleared per use
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;
 }
@@ -754,7 +760,26 @@ __global__ void k_gen_primary(ptgpu_camera cam, int width, int height, float* __
     dir[i * 3] = Rd.x; dir[i * 3 + 1] = Rd.y; dir[i * 3 + 2] = Rd.z;
 }
 
-__global__ void k_gen_shadow(const float* __restrict__ nrm, int num_tris, ptgpu_light L, long long n, const float* __restrict__ orig,
+// shadow ray of BASELINE configs[1] for the hit (tri, t, u, v) of ray (ro, rd) number i: reference src/PathTraceRenderer.cpp:338-344 towards
+// the Sobol light point with index i, dimensions 4 and 5
+// (the two Sobol values come from the byte-indexed pair table: three independent loads instead of up to 2 x 31 dependent trips of
+// sobol::sample's bit loop -- the same words, XOR being associative; i < 2^31)
+__device__ __forceinline__ void shadow_ray(const float* __restrict__ nrm, const uint2* __restrict__ sobol_pairs, const ptgpu_light& L, unsigned long long i,
+                                           ptd::F3 ro, ptd::F3 rd, int tri, float t, float uu, float vv, ptd::F3& o, ptd::F3& d) {
+    ptd::F3 O = ro + t * rd;
+    const float* nn = nrm + (size_t)tri * 9;
+    ptd::F3 N = ptd::normalize((1 - uu - vv) * ptd::ld3(nn) + uu * ptd::ld3(nn + 3) + vv * ptd::ld3(nn + 6));
+    float sa, sb;
+    ptd::sobol32x2(sobol_pairs, (uint32_t)i, 4u, sa, sb);
+    float x = (2.0f * sa - 1.0f) * L.size[0];
+    float y = (2.0f * sb - 1.0f) * L.size[1];
+    ptd::F3 Pl = ptd::f3(L.xform[12], L.xform[13], L.xform[14]) + ptd::f3(L.xform[0], L.xform[1], L.xform[2]) * x +
+                 ptd::f3(L.xform[4], L.xform[5], L.xform[6]) * y;
+    o = O + 0.0001f * N;
+    d = Pl - O;
+}
+
+__global__ void k_gen_shadow(const float* __restrict__ nrm, const uint2* __restrict__ sobol_pairs, int num_tris, ptgpu_light L, long long n, const float* __restrict__ orig,
                              const float* __restrict__ dir, const int32_t* __restrict__ id, const float* __restrict__ t,
                              const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ so, float* __restrict__ sd,
                              int32_t* __restrict__ valid) {
@@ -763,21 +788,80 @@ __global__ void k_gen_shadow(const float* __restrict__ nrm, int num_tris, ptgpu_
     int tri = id[i];
     ptd::F3 o = ptd::f3(0, 0, 0), d = ptd::f3(0, 0, 0);
     if (tri >= num_tris) tri = -1;  // never index past the scene with a caller-supplied id
-    if (tri >= 0) {
-        ptd::F3 O = ptd::ld3(orig + i * 3) + t[i] * ptd::ld3(dir + i * 3);
-        const float* nn = nrm + (size_t)tri * 9;
-        float uu = u[i], vv = v[i];
-        ptd::F3 N = ptd::normalize((1 - uu - vv) * ptd::ld3(nn) + uu * ptd::ld3(nn + 3) + vv * ptd::ld3(nn + 6));
-        float x = (2.0f * ptd::sobol_sample((unsigned long long)i, 4) - 1.0f) * L.size[0];
-        float y = (2.0f * ptd::sobol_sample((unsigned long long)i, 5) - 1.0f) * L.size[1];
-        ptd::F3 Pl = ptd::f3(L.xform[12], L.xform[13], L.xform[14]) + ptd::f3(L.xform[0], L.xform[1], L.xform[2]) * x +
-                     ptd::f3(L.xform[4], L.xform[5], L.xform[6]) * y;
-        o = O + 0.0001f * N;
-        d = Pl - O;
-    }
+    if (tri >= 0) shadow_ray(nrm, sobol_pairs, L, (unsigned long long)i, ptd::ld3(orig + i * 3), ptd::ld3(dir + i * 3), tri, t[i], u[i], v[i], o, d);
     valid[i] = tri >= 0 ? 1 : 0;
     so[i * 3] = o.x; so[i * 3 + 1] = o.y; so[i * 3 + 2] = o.z;
     sd[i * 3] = d.x; sd[i * 3 + 1] = d.y; sd[i * 3 + 2] = d.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BASELINE configs[1] in ONE launch: per pixel the primary ray of k_gen_primary traced closest-hit and, where it hits, the shadow ray of
+// k_gen_shadow traced any-hit -- the rays live in registers, never in HBM (the four-launch form writes and reads 2 x 24 B of ray per
+// pixel and phase and pays three kernel boundaries).  Same device functions, same arithmetic: every output equals the
+// gen_primary -> raycast -> gen_shadow -> raycast sequence bit for bit.  Measured on the 1080p head frame: 0.262 ms against 0.332 ms
+// for the four launches (and 0.321 ms for two launches, one per phase, that re-read the hit record: most of the gain is a wave going
+// straight from its primary rays to its shadow rays).  Per-wave ray counts go to spread counter words (RAY_SPREAD).
+// ------------------------------------------------------------------------------------------------
+template <int NLDS, int TILE_W>
+__global__ __launch_bounds__(64) void k_trace_frame(ptd::TravScene S, const float* __restrict__ nrm, const uint2* __restrict__ sobol_pairs, ptgpu_camera cam,
+                                                          ptgpu_light L, int width, int height, int tiles_x, int32_t* __restrict__ out_id,
+                                                          float* __restrict__ out_t, float* __restrict__ out_u, float* __restrict__ out_v,
+                                                          int32_t* __restrict__ out_shadow_id, unsigned long long* counters) {
+    __shared__ uint2 lds_stack[NLDS][64];
+    constexpr int TILE_H = 64 / TILE_W;
+    const int lane = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
+    const bool have = px < width && py < height;
+    const long long i = (long long)py * width + px;
+    ptd::Trav<false, false, NLDS, false, false> tr;
+    tr.reset_counts();
+    tr.attach(&lds_stack[0][lane], nullptr);
+    tr.alive = false;
+    ptd::F3 Ro = ptd::f3(0, 0, 0), Rd = Ro;
+    if (have) {
+        const float div_x = 1.0f / (float)width, div_y = 1.0f / (float)height;
+        const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+        camera_ray_nodof(cam, fx * div_x * 2.0f - 1.0f, fy * div_y * -2.0f + 1.0f, Ro, Rd);
+        tr.begin(S, Ro, Rd, false);
+    }
+    while (tr.alive) tr.step(S);
+    ptd::HitRec h;
+    h.id = -1; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f;
+    if (have) {
+        h = tr.result(S);
+        out_id[i] = h.id; out_t[i] = h.t; out_u[i] = h.u; out_v[i] = h.v;
+    }
+    const bool shadow = have && h.id >= 0 && out_shadow_id;
+    if (shadow) {
+        ptd::F3 so, sd;
+        shadow_ray(nrm, sobol_pairs, L, (unsigned long long)i, Ro, Rd, h.id, h.t, h.u, h.v, so, sd);
+        tr.begin(S, so, sd, true);
+    }
+    while (tr.alive) tr.step(S);
+    if (have && out_shadow_id) out_shadow_id[i] = shadow ? tr.result(S).id : -1;
+    const unsigned long long rays = (unsigned long long)__popcll(__ballot(have)) + (unsigned long long)__popcll(__ballot(shadow));
+    if (lane == 0 && rays) atomicAdd(&counters[CTR_WORDS + (blockIdx.x & (RAY_SPREAD - 1))], rays);
+}
+
+extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, const ptgpu_light* light, int32_t width, int32_t height, int32_t* d_id,
+                                     float* d_t, float* d_u, float* d_v, int32_t* d_shadow_id) {
+    if (!s || !cam || !light) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (!d_id || !d_t || !d_u || !d_v) return fail(PTGPU_E_INVALID, "the primary hit record arrays are required");
+    if (width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "image size %dx%d", width, height);
+    ptgpu_context* c = s->ctx;
+    if (s->depth - 1 > 24)
+        return fail(PTGPU_E_UNSUPPORTED, "ptgpu_trace_frame_dev: tree depth %d needs more than the 24 LDS stack entries of these kernels; use "
+                    "ptgpu_gen_primary_dev / ptgpu_raycast_batch_dev / ptgpu_gen_shadow_dev", s->depth);
+    HIP_TRY(hipSetDevice(c->device));
+    ptd::TravScene trav = s->trav;
+    trav.alpha_on = 0;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    const dim3 grid((unsigned)(tiles_x * tiles_y));
+    hipLaunchKernelGGL((k_trace_frame<24, 8>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width, (int)height,
+                       tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters);
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
 }
 
 extern "C" int ptgpu_gen_primary_dev(ptgpu_context* c, const ptgpu_camera* cam, int32_t width, int32_t height, float* d_orig, float* d_dir) {
@@ -799,7 +883,8 @@ extern "C" int ptgpu_gen_shadow_dev(ptgpu_scene* s, const ptgpu_light* light, in
     if (!d_orig || !d_dir || !d_id || !d_t || !d_u || !d_v || !d_sh_orig || !d_sh_dir || !d_sh_valid)
         return fail(PTGPU_E_INVALID, "NULL device array");
     HIP_TRY(hipSetDevice(s->ctx->device));
-    hipLaunchKernelGGL(k_gen_shadow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->ctx->stream, s->d_nrm, s->num_tris, *light, (long long)n,
+    if (n > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large (the Sobol index of a shadow ray is its ray index, 31 bits)");
+    hipLaunchKernelGGL(k_gen_shadow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->ctx->stream, s->d_nrm, s->ctx->d_sobol_pairs, s->num_tris, *light, (long long)n,
                        d_orig, d_dir, d_id, d_t, d_u, d_v, d_sh_orig, d_sh_dir, d_sh_valid);
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;

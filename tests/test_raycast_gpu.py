@@ -210,3 +210,37 @@ def test_intersect_triangle1_matches_reference_goldens(gpu_ctx):
     for i, c in enumerate(g):
         if c["hit"]:
             assert got[i].tolist() == c["tuv_bits"], i
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (203, 77)])
+def test_trace_frame_equals_the_four_launch_sequence(gpu_ctx, head_gpu, size, monkeypatch):
+    """ptgpu_trace_frame_dev (primary closest-hit + shadow any-hit with the rays in registers) against
+    gen_primary -> raycast -> gen_shadow -> raycast (itself compared with the oracle in test_config2_full_size): every output word
+    equal, also on an image that is not a whole number of 8x8 wave tiles; one ray counted per pixel plus one per hit."""
+    W, H = size
+    n = W * H
+    cam, light = scene.make_camera(width=W, height=H), scene.make_light()
+    d_o, d_d, d_so, d_sd = (gpu_ctx.malloc(n * 12) for _ in range(4))
+    d_id, d_t, d_u, d_v, d_valid, d_sid = (gpu_ctx.malloc(n * 4) for _ in range(6))
+    gpu_ctx.reset_counters()
+    gpu_ctx.gen_primary_dev(cam, W, H, d_o, d_d)
+    head_gpu.raycast_dev(d_o, d_d, n, False, d_id, d_t, d_u, d_v)
+    head_gpu.gen_shadow_dev(light, n, d_o, d_d, d_id, d_t, d_u, d_v, d_so, d_sd, d_valid)
+    head_gpu.raycast_dev(d_so, d_sd, n, True, d_sid, None, None, None)
+    want = dict(id=gpu_ctx.d2h(d_id, n, np.int32), t=gpu_ctx.d2h(d_t, n, np.uint32), u=gpu_ctx.d2h(d_u, n, np.uint32),
+                v=gpu_ctx.d2h(d_v, n, np.uint32), sid=gpu_ctx.d2h(d_sid, n, np.int32))
+    hits = int((want["id"] >= 0).sum())
+    assert gpu_ctx.counters()["rays"] == 2 * n and hits > n // 10  # the separate form also "traces" the empty rays of missed pixels
+    f_id, f_t, f_u, f_v, f_sid = (gpu_ctx.malloc(n * 4) for _ in range(5))
+    for tile_w in ("8",):
+        for p in (f_id, f_t, f_u, f_v, f_sid):
+            capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, p, 0xEE, n * 4))
+        gpu_ctx.reset_counters()
+        head_gpu.trace_frame_dev(cam, light, W, H, f_id, f_t, f_u, f_v, f_sid)
+        got = dict(id=gpu_ctx.d2h(f_id, n, np.int32), t=gpu_ctx.d2h(f_t, n, np.uint32), u=gpu_ctx.d2h(f_u, n, np.uint32),
+                   v=gpu_ctx.d2h(f_v, n, np.uint32), sid=gpu_ctx.d2h(f_sid, n, np.int32))
+        for k in want:
+            assert np.array_equal(got[k], want[k]), "tile_w=%s: %s differs in %d places" % (tile_w, k, int((got[k] != want[k]).sum()))
+        assert gpu_ctx.counters()["rays"] == n + hits  # one raycast() per pixel plus one per hit
+    for p in (d_o, d_d, d_so, d_sd, d_id, d_t, d_u, d_v, d_valid, d_sid, f_id, f_t, f_u, f_v, f_sid):
+        gpu_ctx.free(p)

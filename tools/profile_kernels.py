@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Short, fixed launch sequence for rocprofv3 (kernel trace or one --pmc pass per run):
-  5 x configs[1] frame (gen_primary, raycast closest, gen_shadow, raycast any-hit) on head.obj 1920x1080, then
+  5 x configs[1] frame as bench.py's step runs it (ptgpu_trace_frame_dev, one launch) and 5 x as four launches (gen_primary, raycast
+  closest, gen_shadow, raycast any-hit) on head.obj 1920x1080, then
   1 x path-trace pass of the configs[2] frame at 16 spp (Gaussian AA, textures + normal maps, RR).
 Usage on the GPU box:   rocprofv3 --kernel-trace --stats ... -- python3 tools/profile_kernels.py
                         rocprofv3 --pmc FETCH_SIZE ... -- python3 tools/profile_kernels.py"""
@@ -32,6 +33,8 @@ def main():
     t, u, v = (torch.empty(n, **f) for _ in range(3))
     hid, valid, sid = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
     P = lambda x: x.data_ptr()  # noqa: E731
+    for _ in range(5):
+        sc.trace_frame_dev(cam, light, W, H, P(hid), P(t), P(u), P(v), P(sid))
     for _ in range(5):
         ctx.gen_primary_dev(cam, W, H, P(o), P(d))
         sc.raycast_dev(P(o), P(d), n, False, P(hid), P(t), P(u), P(v))

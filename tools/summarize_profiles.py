@@ -56,7 +56,8 @@ def main():
     json.dump(keep, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     # what bench.py reads: one entry per kernel of the bench line's rooflines
     traffic = {}
-    want = {"k_raycast_closest": "k_raycast_step<false", "k_raycast_anyhit": "k_raycast_step<true", "k_integrate": "k_integrate"}
+    want = {"k_raycast_closest": "k_raycast_step<false", "k_raycast_anyhit": "k_raycast_step<true", "k_integrate": "k_integrate",
+            "k_trace_frame": "k_trace_frame"}
     fields = ("hbm_bytes_corrected", "hbm_bytes_raw", "l2_hit_rate", "valu_active_frac_of_wave_cycles", "valu_lane_utilisation",
               "avg_duration_us", "launches", "vgpr", "lds_bytes")
     for key, prefix in want.items():
