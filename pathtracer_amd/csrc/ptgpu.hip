@@ -856,10 +856,14 @@ extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, co
     HIP_TRY(hipSetDevice(c->device));
     ptd::TravScene trav = s->trav;
     trav.alpha_on = 0;
-    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    const int tw = env_int("PTGPU_FRAME_TILE_W", 8);
+    const int th = 64 / tw;
+    const int tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
     const dim3 grid((unsigned)(tiles_x * tiles_y));
-    hipLaunchKernelGGL((k_trace_frame<24, 8>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width, (int)height,
-                       tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters);
+#define PT_FRAME(TW) hipLaunchKernelGGL((k_trace_frame<24, TW>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width, \
+                                        (int)height, tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters)
+    if (tw == 4) PT_FRAME(4); else if (tw == 16) PT_FRAME(16); else if (tw == 32) PT_FRAME(32); else if (tw == 64) PT_FRAME(64); else PT_FRAME(8);
+#undef PT_FRAME
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;
 }

@@ -40,12 +40,12 @@ def fused():
     sc.trace_frame_dev(cam, light, W, H, P(hid), P(t), P(u), P(v), P(sid))
 
 
-variants = [("four launches", four, "0"), ("one launch", fused, "1")]
+variants = [("four launches", four, "8")] + [("one launch %dx%d" % (w, 64 // w), fused, str(w)) for w in (4, 8, 16, 32, 64)]
 times = {k: [] for k, _, _ in variants}
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     for name, fn, tile in variants:
-        os.environ["PTGPU_FRAME_FUSED"] = tile
+        os.environ["PTGPU_FRAME_TILE_W"] = tile
         fn()
         ev[0].record(stream)
         for _ in range(20):
@@ -56,4 +56,4 @@ for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
             times[name].append(ev[0].elapsed_time(ev[1]) / 20)
 for name, _, _ in variants:
     a = np.array(times[name])
-    print("%-14s median %.4f ms  min %.4f ms" % (name, np.median(a), a.min()), flush=True)
+    print("%-18s median %.4f ms  min %.4f ms" % (name, np.median(a), a.min()), flush=True)
