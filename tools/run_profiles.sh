@@ -14,7 +14,7 @@ run() { # name, rocprofv3 args...
     return $rc
 }
 # the bench command itself (the bench line's kernel durations must agree with this trace)
-timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/benchcmd" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > "$OUT/benchcmd.log" 2>&1
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/benchcmd" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-extra > "$OUT/benchcmd.log" 2>&1
 echo "pass benchcmd rc=$?"
 run trace --kernel-trace --stats &&
 run fetch --pmc FETCH_SIZE &&
