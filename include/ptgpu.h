@@ -33,6 +33,7 @@ extern "C" {
 #define PTGPU_E_HIP (-2)       /* a HIP runtime call failed */
 #define PTGPU_E_NODEVICE (-3)  /* no usable gfx950 device */
 #define PTGPU_E_UNSUPPORTED (-4)
+#define PTGPU_E_INTERNAL (-5)  /* a device-side safety limit ended a launch early (message says which); the call's output is incomplete */
 
 typedef struct ptgpu_context ptgpu_context;
 typedef struct ptgpu_scene ptgpu_scene;
@@ -239,7 +240,8 @@ int ptgpu_resolve_dev(ptgpu_context* ctx, const float* d_accum, int32_t width, i
  * pixel outside its block, src/PathTraceRenderer.cpp:714-728, p = 2^-24 per coordinate): out[0] = how many there were, out[1] = how many
  * were DROPPED because a list was full (0 in any sane render; ptgpu_render_pass reports it as an error, callers of the _dev variant
  * ask here), out[2] = entries waiting in the foreign list (samples that landed in a block of another rank, delivered by
- * ptgpu_gather_tiles_dev / ptgpu_tiles_pack_dev).  Synchronises the context's stream. */
+ * ptgpu_gather_tiles_dev / ptgpu_tiles_pack_dev).  Synchronises the context's stream.  Returns PTGPU_E_INTERNAL if the last pass ran the
+ * experimental pooled integrator (environment PTGPU_PT_POOL=1) and its watchdog ended a launch early. */
 int ptgpu_spill_status(ptgpu_context* ctx, uint64_t out[3]);
 
 /* ---- image tiles across the GPUs of one node (one process and one context per GPU).  No counterpart in the reference, whose worker

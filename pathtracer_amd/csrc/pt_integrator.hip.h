@@ -366,7 +366,7 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
     };
 
 #ifdef PT_STAMPS
-    long long st_cyc[7] = {0, 0, 0, 0, 0, 0, 0}, st_inv[7] = {0, 0, 0, 0, 0, 0, 0}, st_lanes[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long st_cyc[7] = {0, 0, 0, 0, 0, 0, 0}, st_inv[7] = {0, 0, 0, 0, 0, 0, 0}, st_lanes[7] = {0, 0, 0, 0, 0, 0, 0}, st_phase[3] = {0, 0, 0};
 #endif
     // Whitted: next disk sample of the chosen light and its shadow ray (shared tail of the hit and shade blocks)
     auto whitted_shadow = [&]() {
@@ -712,6 +712,13 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
 #ifndef PT_UNPHASED_STEPS
             {
                 const bool node_lane = tr.alive && tr.at_node(), tri_lane = tr.alive && !tr.at_node();
+#ifdef PT_STAMPS
+                {   // lanes of the chosen kind at the phase's first step (word 29), node phases (30), node lanes + triangle lanes (31)
+                    const int nn_ = __popcll(__ballot(node_lane)), nt_ = __popcll(__ballot(tri_lane));
+                    const bool np_ = nn_ * PT_PHASE_BIAS_N >= nt_ * PT_PHASE_BIAS_T;
+                    st_phase[0] += np_ ? nn_ : nt_; st_phase[1] += np_ ? 1 : 0; st_phase[2] += nn_ + nt_;
+                }
+#endif
                 if (__popcll(__ballot(node_lane)) * PT_PHASE_BIAS_N >= __popcll(__ballot(tri_lane)) * PT_PHASE_BIAS_T) {
                     if (tr.alive && tr.at_node()) tr.step_node(TS);
 #if PT_PHASE_NODE_REPS >= 2
@@ -759,6 +766,8 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
             atomicAdd(&counters[9 + 3 * k], (unsigned long long)st_inv[k]);
             atomicAdd(&counters[10 + 3 * k], (unsigned long long)st_lanes[k]);
         }
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) atomicAdd(&counters[29 + k], (unsigned long long)st_phase[k]);
 #endif
     // 1 ray = 1 raycast() call (reference src/RayTracer.cpp:192)
     unsigned long long wr = n_rays;

@@ -15,6 +15,7 @@
 #include "pt_traverse.hip.h"
 #include "pt_raycast_step.h"
 #include "pt_integrator.hip.h"
+#include "pt_integrator_pool.hip.h"
 #include "pt_lbvh.hip.h"
 
 namespace ptd {
@@ -215,7 +216,7 @@ extern "C" int ptgpu_get_counters(ptgpu_context* c, ptgpu_counters* out) {
     for (int i = 0; i < RAY_SPREAD; ++i) out->rays += h[CTR_WORDS + i];
     return PTGPU_OK;
 }
-#ifdef PT_STAMPS
+#if defined(PT_STAMPS) || defined(PT_POOL_STATS)
 // Diagnostic builds only (not declared in include/ptgpu.h, absent from the shipped library): raw copy of all counter words.
 extern "C" int ptgpu_debug_counters(ptgpu_context* c, unsigned long long* out32) {
     if (!c || !out32) return fail(PTGPU_E_INVALID, "NULL argument");
@@ -931,6 +932,15 @@ ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
                                                OVF ? stack_ovf + wave_id * (64 - NLDS) * 64 + lane : nullptr, service_threshold);
 }
 
+// the pooled form (csrc/pt_integrator_pool.hip.h): one large workgroup per CU, path state in LDS slots, trace waves + shade waves
+template <bool ALPHA>
+__global__ __launch_bounds__(ptd::POOL_THREADS) void k_integrate_pool(ptd::TravScene TS, ptd::ShadeScene SS, ptgpu_params prm, ptgpu_camera cam,
+                                                                      const ptgpu_light* __restrict__ lights, ptd::PassDesc pd, float4* __restrict__ rad,
+                                                                      unsigned long long* counters, uint2* stack_ovf, ptd::PoolCold* cold, int knobs) {
+    extern __shared__ __align__(16) unsigned char pool_smem[];
+    ptd::integrate_pool<ptd::POOL_NLDS, ALPHA>(TS, SS, prm, cam, lights, pd, rad, counters, pool_smem, stack_ovf, cold, knobs);
+}
+
 __device__ __forceinline__ void block_rect(const ptgpu_params& prm, const ptd::PassDesc& pd, int jj, int& bx, int& by, int& bw, int& bh) {
     const int idx = pd.block_begin + (pd.j0 + jj) * pd.block_stride;
     bx = (idx % pd.blocks_x) * 32; by = (idx / pd.blocks_x) * 32;
@@ -1131,6 +1141,29 @@ static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const pt
     return PTGPU_OK;
 }
 
+template <bool ALPHA>
+static int launch_integrate_pool(ptgpu_scene* s, const ptd::TravScene& trav, const ptd::ShadeScene& ss, const ptgpu_params* prm, const ptgpu_camera* cam,
+                                 const ptd::PassDesc& pd) {
+    ptgpu_context* c = s->ctx;
+    const size_t lds = ptd::pool_lds_bytes();
+    static std::atomic<int> attr_set{0};
+    if (!attr_set.load(std::memory_order_relaxed)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_integrate_pool<ALPHA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.store(1, std::memory_order_relaxed);
+    }
+    const long long total = (long long)pd.num_blocks * pd.samples_per_block;
+    long long blocks = (total + ptd::POOL_CHUNK - 1) / ptd::POOL_CHUNK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > c->num_cu) blocks = c->num_cu;  // one workgroup per CU (LDS-bound), resident for the whole launch
+    // one allocation: the trace waves' stack overflow regions, then the slots' shade-only state
+    const size_t ovf_bytes = (size_t)blocks * ptd::POOL_TW * ptd::stack_overflow_bytes_per_wave<ptd::POOL_NLDS>();
+    int rc = ensure_stack_overflow(c, ovf_bytes + (size_t)blocks * ptd::pool_cold_bytes_per_group());
+    if (rc != PTGPU_OK) return rc;
+    hipLaunchKernelGGL((k_integrate_pool<ALPHA>), dim3((unsigned)blocks), dim3(ptd::POOL_THREADS), lds, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
+                       c->d_counters, c->d_stack_ovf, reinterpret_cast<ptd::PoolCold*>(reinterpret_cast<unsigned char*>(c->d_stack_ovf) + ovf_bytes), env_int("PTGPU_POOL_REFILL", 16) | (env_int("PTGPU_POOL_LOW", 32) << 8));
+    return PTGPU_OK;
+}
+
 extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, const ptgpu_camera* cam, const ptgpu_light* lights, int32_t num_lights,
                                      int32_t block_begin, int32_t block_end, int32_t block_stride, float* d_accum) {
     if (!s || !prm || !cam || !lights || !d_accum) return fail(PTGPU_E_INVALID, "NULL argument");
@@ -1150,6 +1183,8 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     if (rc != PTGPU_OK) return rc;
     // spill list and dropped-sample count are per pass (all batches of this call append to one list, applied after the last block sum)
     if (prm->sobol_block) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + CTR_SPILL, 2);
+    const bool pooled = env_int("PTGPU_PT_POOL", 0) != 0;  // the pooled form of the integrator (csrc/pt_integrator_pool.hip.h), off unless asked for
+    if (pooled) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + ptd::CTR_POOL_ABORT, 1);
     const int count = (block_end - block_begin + block_stride - 1) / block_stride;  // blocks of this call
     const long long spb = 1024LL * prm->num_aa_rays;
     // samples per integrator launch: every launch ends with a tail of waves draining, so few, large launches (the radiance buffer is
@@ -1183,7 +1218,10 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
         // the alpha-cutout code is only compiled into the variants a scene with alpha maps takes (fewer registers for all others)
 #define PT_LAUNCH(COUNT_, NLDS_, OVF_) (trav.alpha_on ? launch_integrate<COUNT_, NLDS_, OVF_, true>(s, trav, ss, prm, cam, pd) \
                                                       : launch_integrate<COUNT_, NLDS_, OVF_, false>(s, trav, ss, prm, cam, pd))
-        if (c->count) rc = launch_integrate<true, 16, true, true>(s, trav, ss, prm, cam, pd);
+        const int abs_bounces = prm->bounces < 0 ? -prm->bounces : prm->bounces;
+        if (pooled && !c->count && !prm->whitted && abs_bounces < 60000)
+            rc = trav.alpha_on ? launch_integrate_pool<true>(s, trav, ss, prm, cam, pd) : launch_integrate_pool<false>(s, trav, ss, prm, cam, pd);
+        else if (c->count) rc = launch_integrate<true, 16, true, true>(s, trav, ss, prm, cam, pd);
         else if (nlds == 12) rc = PT_LAUNCH(false, 12, true);
         else if (stack_need > 24 || (stack_need > 16 && nlds == 16)) rc = PT_LAUNCH(false, 16, true);
         else if (nlds == 16) rc = PT_LAUNCH(false, 16, false);
@@ -1207,11 +1245,14 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
 
 extern "C" int ptgpu_spill_status(ptgpu_context* c, uint64_t out[3]) {
     if (!c || !out) return fail(PTGPU_E_INVALID, "NULL argument");
-    unsigned long long h[4];
+    unsigned long long h[5];
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(h, c->d_counters + CTR_SPILL, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[CTR_FOREIGN - CTR_SPILL] < (unsigned long long)FOREIGN_CAPACITY ? h[CTR_FOREIGN - CTR_SPILL] : FOREIGN_CAPACITY;
+    if (h[ptd::CTR_POOL_ABORT - CTR_SPILL] != 0)
+        return fail(PTGPU_E_INTERNAL, "the pooled integrator (PTGPU_PT_POOL=1) gave a launch up after a wave waited %lld ticks: the pass's image is incomplete",
+                    (long long)ptd::POOL_WATCHDOG_TICKS);
     return PTGPU_OK;
 }
 

@@ -1,0 +1,10 @@
+#!/bin/bash
+# A/B builds of the same ABI with compile-time knobs: tools/build_variant.sh NAME [-DKNOB=V ...] -> build/libptgpu_NAME.so
+# (load with PTGPU_LIB=build/libptgpu_NAME.so; only csrc/ptgpu.hip is recompiled, the other objects come from the normal build)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+F="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-result -Wno-unused-value"
+/opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=iterative-ilp "$@" -c -o build/ptgpu_$name.o pathtracer_amd/csrc/ptgpu.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o build/libptgpu_$name.so build/ptgpu_$name.o build/pt_raycast_step.o build/pt_multigpu.o -ldl
+echo build/libptgpu_$name.so

@@ -36,14 +36,17 @@ int main()
     uint32_t x = 12345u;
     for (auto& v : h) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v = x; }
     uint4* d_rec; uint32_t* d_out;
-    const int groups = 256 * 16 * 4, iters = 3000;  // 16 waves per CU resident (4 per SIMD, as k_integrate runs), 4 rounds
+    const int iters = 3000;
     CK(hipMalloc(&d_rec, h.size() * 4));
-    CK(hipMalloc(&d_out, (size_t)groups * 64 * 4));
+    CK(hipMalloc(&d_out, (size_t)256 * 32 * 4 * 64 * 4));
     CK(hipMemcpy(d_rec, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int spread = 0; spread < 2; ++spread)
+    // resident waves per CU: one round of 256 x W single-wave workgroups (all resident at once), except the first line set: 16 per CU, 4 rounds
+    for (int wpc : {0, 4, 8, 16, 32})
+    for (int spread = 0; spread < (wpc ? 1 : 2); ++spread)
         for (int k : {8, 16, 24, 32, 40, 48, 56, 64}) {
+            const int groups = wpc ? 256 * wpc : 256 * 16 * 4;
             k_gather<<<groups, 64>>>(d_rec, records - 1, iters / 10, d_out, k, spread);
             CK(hipDeviceSynchronize());
             float best = 1e30f;
@@ -56,8 +59,8 @@ int main()
                 if (ms < best) best = ms;
             }
             const double wave_steps = (double)groups * iters, lane_steps = wave_steps * k;
-            printf("{\"active_lanes\": %d, \"spread\": %d, \"ms\": %.3f, \"Gwave_steps_per_s\": %.2f, \"Glane_steps_per_s\": %.1f, \"GB_per_s\": %.0f, "
-                   "\"cycles_per_wave_step_per_CU\": %.1f}\n", k, spread, best, wave_steps / best * 1e-6, lane_steps / best * 1e-6,
+            printf("{\"waves_per_cu\": %d, \"active_lanes\": %d, \"spread\": %d, \"ms\": %.3f, \"Gwave_steps_per_s\": %.2f, \"Glane_steps_per_s\": %.1f, \"GB_per_s\": %.0f, "
+                   "\"cycles_per_wave_step_per_CU\": %.1f}\n", wpc ? wpc : 16, k, spread, best, wave_steps / best * 1e-6, lane_steps / best * 1e-6,
                    lane_steps * 64 / best * 1e-6, best * 1e-3 * 2.4e9 * 256 / wave_steps);
             fflush(stdout);
         }

@@ -32,3 +32,5 @@ for sobol_block in (True, False):
     for k, nme in enumerate(names):
         cyc, inv, lanes = d[8 + 3 * k], d[9 + 3 * k], d[10 + 3 * k]
         print("  %-8s cycles %5.1f%%  invocations %10d  cycles/inv %8.1f  lanes/inv %5.1f" % (nme, 100.0 * cyc / tot, inv, cyc / max(inv, 1), lanes / max(inv, 1)))
+    steps = d[9 + 18]
+    print("  phase: lanes of the chosen kind at its first step %.1f, node phases %.1f%%, alive lanes %.1f" % (d[29] / steps, 100.0 * d[30] / steps, d[31] / steps))
