@@ -104,6 +104,9 @@ def roofline(kernel, alg_bytes, ms, prof, note):
                    "algorithmic_over_hbm_peak": achieved / HBM_PEAK_GBS},
            "l2_hit": prof.get("l2_hit_rate"), "valu_util": prof.get("valu_active_frac_of_wave_cycles"),
            "valu_lane_util": prof.get("valu_lane_utilisation"),
+           # vector memory path (texture-data / texture-address units' busy cycles over the kernel's cycles, rocprofv3 --pmc): the unit
+           # that is closest to saturation in every traversal kernel here
+           "td_busy": prof.get("td_busy_frac"), "ta_busy": prof.get("ta_busy_frac"),
            "measured_gather_ceiling": {"coherent": GATHER_COHERENT_GBS, "incoherent": GATHER_INCOHERENT_GBS, "unit": "GB/s",
                                        "frac_of_coherent": achieved / GATHER_COHERENT_GBS},
            "note": note}
@@ -413,7 +416,8 @@ def extra_legs(ctx, stream, dev):
         out.append({"workload": name, "triangles": int(m["pos"].shape[0]), "bvh_nodes": int(nodes.shape[0]), "host_sah_build_s": build_s,
                     "primary_Mrays_per_s": n / (ms * 1e-3) / 1e6, "primary_ms": ms,
                     "per_ray": {"nodes": c["node_visits"] / n, "tris": c["tri_tests"] / n, "bytes": alg / n},
-                    "primary_algorithmic_GBps": alg / (ms * 1e-3) / 1e9, "primary_frac_of_l2_gather_peak": alg / (ms * 1e-3) / 1e9 / L2_GATHER_PEAK_GBS,
+                    "primary_algorithmic_GBps": alg / (ms * 1e-3) / 1e9,  # no fraction: neighbouring 4K rays read the SAME records (one fetch serves
+                    # many lanes), so algorithmic bytes can exceed what any data path moved
                     "path_trace": {"spp": spp, "samples_per_s": n * spp / (pt_ms * 1e-3), "Mrays_per_s": rays / (pt_ms * 1e-3) / 1e6, "ms": pt_ms}})
         s.close()
         del o, d, t, u, v, hid, accum, sd, m

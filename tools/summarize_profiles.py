@@ -51,6 +51,13 @@ def main():
             d["valu_active_frac_of_wave_cycles"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
         if "SQ_THREAD_CYCLES_VALU" in d and "SQ_ACTIVE_INST_VALU" in d and d["SQ_ACTIVE_INST_VALU"] > 0:
             d["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
+        # vector memory path: busy cycles of the texture-address / texture-data units summed over 256 CUs against the kernel's cycles
+        # (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+        if "TD_TD_BUSY_sum" in d and d.get("GRBM_GUI_ACTIVE", 0) > 0:
+            d["td_busy_frac"] = (d["TD_TD_BUSY_sum"] / 256.0) / (d["GRBM_GUI_ACTIVE"] / 8.0)
+            d["ta_busy_frac"] = (d["TA_TA_BUSY_sum"] / 256.0) / (d["GRBM_GUI_ACTIVE"] / 8.0)
+            if d.get("TA_FLAT_READ_WAVEFRONTS_sum", 0) > 0:
+                d["td_busy_cycles_per_vmem_wave_instruction"] = d["TD_TD_BUSY_sum"] / d["TA_FLAT_READ_WAVEFRONTS_sum"]
     keep = {k: v for k, v in out.items() if k.startswith("k_")}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(keep, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
@@ -58,7 +65,7 @@ def main():
     traffic = {}
     want = {"k_raycast_closest": "k_raycast_step<false", "k_raycast_anyhit": "k_raycast_step<true", "k_integrate": "k_integrate",
             "k_trace_frame": "k_trace_frame"}
-    fields = ("hbm_bytes_corrected", "hbm_bytes_raw", "l2_hit_rate", "valu_active_frac_of_wave_cycles", "valu_lane_utilisation",
+    fields = ("hbm_bytes_corrected", "hbm_bytes_raw", "l2_hit_rate", "valu_active_frac_of_wave_cycles", "valu_lane_utilisation", "td_busy_frac", "ta_busy_frac",
               "avg_duration_us", "launches", "vgpr", "lds_bytes")
     for key, prefix in want.items():
         for k, v in keep.items():
