@@ -87,6 +87,7 @@ SIGNATURES = [
     ("ptgpu_get_counters", C.c_int, [_P, C.POINTER(Counters)]),
     ("ptgpu_reset_counters", C.c_int, [_P]),
     ("ptgpu_scene_create", C.c_int, [_P, C.POINTER(SceneDesc), C.POINTER(_P)]),
+    ("ptgpu_scene_create_lbvh", C.c_int, [_P, C.POINTER(SceneDesc), C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("ptgpu_scene_destroy", C.c_int, [_P]),
     ("ptgpu_scene_stats", C.c_int, [_P, C.POINTER(C.c_uint64 * 4), C.POINTER(C.c_int32)]),
     ("ptgpu_raycast_batch", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
@@ -315,11 +316,23 @@ def make_scene_desc(sd):
 
 
 class Scene:
-    def __init__(self, ctx, sd):
+    def __init__(self, ctx, sd, lbvh_max_tris_in_leaf=None):
+        """sd: scene dict (triangle arrays, materials, textures, nodes, list).  lbvh_max_tris_in_leaf: build the hierarchy on the device
+        instead (ptgpu_scene_create_lbvh; sd's nodes / list are ignored) -- num_nodes_built then holds the built tree's node count."""
         self.ctx, self.lib = ctx, ctx.lib
-        desc, keep = make_scene_desc(sd)
         h = _P()
-        _check(self.lib.ptgpu_scene_create(ctx.handle, C.byref(desc), C.byref(h)))
+        self.num_nodes_built = None
+        if lbvh_max_tris_in_leaf is None:
+            desc, keep = make_scene_desc(sd)
+            _check(self.lib.ptgpu_scene_create(ctx.handle, C.byref(desc), C.byref(h)))
+        else:
+            sd2 = dict(sd)
+            sd2["nodes"], sd2["list"] = np.zeros(0, FLATNODE_DTYPE), np.zeros(0, np.int32)
+            desc, keep = make_scene_desc(sd2)
+            desc.nodes, desc.list = None, None
+            nn = C.c_int32()
+            _check(self.lib.ptgpu_scene_create_lbvh(ctx.handle, C.byref(desc), int(lbvh_max_tris_in_leaf), C.byref(h), C.byref(nn)))
+            self.num_nodes_built = nn.value
         self.handle = h
 
     def close(self):

@@ -50,6 +50,7 @@ struct ptgpu_scene {
     ptgpu_context* ctx = nullptr;
     ptd::TravScene trav{};
     int32_t num_tris = 0, num_inner = 0, depth = 0;
+    int32_t num_nodes_built = 0;  // ptgpu_scene_create_lbvh: nodes of the tree the device built
     bool has_alpha = false;
     // device allocations
     float4* d_records = nullptr;  // triangle records in reverse order, then the interior records (TravScene::records points between them)
@@ -249,7 +250,8 @@ static int child_ref(const ptgpu_flatnode* nodes, const std::vector<int32_t>& in
     return nodes[child].leaf ? ~nodes[child].startIdx : inner_index[child];
 }
 
-static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene* s) {
+// triangle / material / texture arrays of a scene description (everything but the hierarchy)
+static int check_scene_arrays(const ptgpu_scene_desc* d) {
     const int32_t nn = d->num_nodes, nl = d->list_size, nt = d->num_tris;
     if (nt < 0 || nn < 0 || nl < 0) return fail(PTGPU_E_INVALID, "negative count in scene description");
     if (nt > 0 && (!d->pos || !d->nrm || !d->uv || !d->mat_id || !d->woop))
@@ -267,6 +269,37 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
     for (int i = 0; i < d->num_textures; ++i)
         if (d->textures[i].width < 2 || d->textures[i].height < 2 || !d->textures[i].rgba)
             return fail(PTGPU_E_INVALID, "texture %d: needs width,height >= 2 and pixel data", i);
+    return PTGPU_OK;
+}
+
+// the arrays shading reads (never touched by traversal)
+static int upload_shading_arrays(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene* s) {
+    const int32_t nt = d->num_tris;
+    int rc;
+    if ((rc = upload(c, &s->d_pos, d->pos, (size_t)nt * 9, &s->bytes[2]))) return rc;
+    if ((rc = upload(c, &s->d_nrm, d->nrm, (size_t)nt * 9, &s->bytes[2]))) return rc;
+    if ((rc = upload(c, &s->d_uv, d->uv, (size_t)nt * 6, &s->bytes[2]))) return rc;
+    if ((rc = upload(c, &s->d_mat_id, d->mat_id, (size_t)nt, &s->bytes[2]))) return rc;
+    if ((rc = upload(c, &s->d_materials, d->materials, (size_t)d->num_materials, &s->bytes[2]))) return rc;
+    std::vector<ptd::DevTexture> tex(d->num_textures);
+    for (int i = 0; i < d->num_textures; ++i) {
+        uint8_t* p = nullptr;
+        if ((rc = upload(c, &p, d->textures[i].rgba, (size_t)d->textures[i].width * d->textures[i].height * 4, &s->bytes[3]))) return rc;
+        s->d_texels.push_back(p);
+        tex[i].rgba = p; tex[i].width = d->textures[i].width; tex[i].height = d->textures[i].height;
+    }
+    if ((rc = upload(c, &s->d_textures, tex.data(), tex.size(), &s->bytes[3]))) return rc;
+    s->trav.uv = s->d_uv;
+    s->trav.textures = s->d_textures;
+    return PTGPU_OK;
+}
+
+static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene* s) {
+    const int32_t nn = d->num_nodes, nl = d->list_size, nt = d->num_tris;
+    {
+        const int rc0 = check_scene_arrays(d);
+        if (rc0 != PTGPU_OK) return rc0;
+    }
 
     s->num_tris = nt;
     s->num_materials = d->num_materials;
@@ -368,22 +401,7 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
         s->bytes[1] += tris.size() * sizeof(float4);
         s->trav.records = s->d_records + n_tri_rec * 4;
     }
-    if ((rc = upload(c, &s->d_pos, d->pos, (size_t)nt * 9, &s->bytes[2]))) return rc;
-    if ((rc = upload(c, &s->d_nrm, d->nrm, (size_t)nt * 9, &s->bytes[2]))) return rc;
-    if ((rc = upload(c, &s->d_uv, d->uv, (size_t)nt * 6, &s->bytes[2]))) return rc;
-    if ((rc = upload(c, &s->d_mat_id, d->mat_id, (size_t)nt, &s->bytes[2]))) return rc;
-    if ((rc = upload(c, &s->d_materials, d->materials, (size_t)d->num_materials, &s->bytes[2]))) return rc;
-    std::vector<ptd::DevTexture> tex(d->num_textures);
-    for (int i = 0; i < d->num_textures; ++i) {
-        uint8_t* p = nullptr;
-        if ((rc = upload(c, &p, d->textures[i].rgba, (size_t)d->textures[i].width * d->textures[i].height * 4, &s->bytes[3]))) return rc;
-        s->d_texels.push_back(p);
-        tex[i].rgba = p; tex[i].width = d->textures[i].width; tex[i].height = d->textures[i].height;
-    }
-    if ((rc = upload(c, &s->d_textures, tex.data(), tex.size(), &s->bytes[3]))) return rc;
-    s->trav.uv = s->d_uv;
-    s->trav.textures = s->d_textures;
-    return PTGPU_OK;
+    return upload_shading_arrays(c, d, s);
 }
 
 extern "C" int ptgpu_scene_destroy(ptgpu_scene* s) {
@@ -1508,31 +1526,36 @@ extern "C" int ptgpu_intersect_triangle1_batch(ptgpu_context* c, const float* or
 // ------------------------------------------------------------------------------------------------
 // Device-side BVH builder (pt_lbvh.hip.h): host arrays in, reference-layout tree out
 // ------------------------------------------------------------------------------------------------
-extern "C" int ptgpu_bvh_build_lbvh(ptgpu_context* c, const float* pos, int32_t num_tris, int32_t max_tris_in_leaf, ptgpu_flatnode* out_nodes,
-                                    int32_t* out_num_nodes, int32_t* out_list, int32_t* out_depth) {
-    if (!c || !out_num_nodes) return fail(PTGPU_E_INVALID, "NULL argument");
-    if (num_tris < 0) return fail(PTGPU_E_INVALID, "num_tris < 0");
-    if (max_tris_in_leaf < 1) return fail(PTGPU_E_INVALID, "max_tris_in_leaf %d < 1", max_tris_in_leaf);
-    if (num_tris > 0 && (!pos || !out_nodes || !out_list)) return fail(PTGPU_E_INVALID, "NULL array");
-    *out_num_nodes = 0;
-    if (out_depth) *out_depth = 0;
-    if (num_tris == 0) return PTGPU_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    const int n = num_tris;
-    hipStream_t st = c->stream;
-    // everything in one allocation list so that every exit path frees it
+namespace {
+// what the device builder leaves on the device (freed by release())
+struct LbvhOnDevice {
     std::vector<void*> owned;
-    auto cleanup = [&]() { for (void* p : owned) hipFree(p); };
+    ptgpu_flatnode* d_nodes = nullptr;  // reference layout, pre-order
+    int32_t* d_list = nullptr;          // triangle index per list entry
+    int32_t num_nodes = 0, depth = 0;
+    void release() { for (void* p : owned) hipFree(p); owned.clear(); }
+};
+}  // namespace
+
+// num_tris >= 2.  The triangle positions come from the host (`pos`) or, if d_pos_ready is not NULL, are on the device already.
+static int lbvh_build_on_device(ptgpu_context* c, const float* pos, const float* d_pos_ready, int n, int max_tris_in_leaf, LbvhOnDevice& R) {
+    hipStream_t st = c->stream;
+    auto cleanup = [&]() { R.release(); };
     auto dalloc = [&](size_t bytes) -> void* {
         void* p = nullptr;
         if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
-        owned.push_back(p);
+        R.owned.push_back(p);
         return p;
     };
 #define LB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(PTGPU_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
 #define LB_ALLOC(var, type, count) type* var = (type*)dalloc((size_t)(count) * sizeof(type)); if (!var) { cleanup(); return fail(PTGPU_E_HIP, "hipMalloc failed in the BVH builder"); }
     const int n_int = n - 1;
-    LB_ALLOC(d_pos, float, (size_t)n * 9)
+    const float* d_pos = d_pos_ready;
+    if (!d_pos) {
+        LB_ALLOC(d_pos_own, float, (size_t)n * 9)
+        LB_TRY(hipMemcpyAsync(d_pos_own, pos, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, st));
+        d_pos = d_pos_own;
+    }
     LB_ALLOC(d_lo, float4, n)
     LB_ALLOC(d_hi, float4, n)
     LB_ALLOC(d_bounds, uint32_t, 8)
@@ -1542,7 +1565,6 @@ extern "C" int ptgpu_bvh_build_lbvh(ptgpu_context* c, const float* pos, int32_t 
     LB_ALLOC(d_vals2, int32_t, n)
     LB_ALLOC(d_out, int32_t, 4)
     const uint32_t h_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
-    LB_TRY(hipMemcpyAsync(d_pos, pos, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, st));
     LB_TRY(hipMemcpyAsync(d_bounds, h_bounds, sizeof h_bounds, hipMemcpyHostToDevice, st));
     LB_TRY(hipMemsetAsync(d_out, 0, 4 * sizeof(int32_t), st));
     const unsigned blocks = (unsigned)((n + 255) / 256);
@@ -1556,24 +1578,6 @@ extern "C" int ptgpu_bvh_build_lbvh(ptgpu_context* c, const float* pos, int32_t 
     LB_TRY(hipMemcpyAsync(hb, d_bounds, sizeof hb, hipMemcpyDeviceToHost, st));
     LB_TRY(hipStreamSynchronize(st));
     if (hb[6]) { cleanup(); return fail(PTGPU_E_INVALID, "a triangle has a vertex that is not finite"); }
-    LB_TRY(hipMemcpyAsync(out_list, d_vals2, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (n == 1) {
-        LB_TRY(hipStreamSynchronize(st));
-        ptgpu_flatnode f;
-        memset(&f, 0, sizeof f);
-        float mn[3], mx[3];
-        for (int k = 0; k < 3; ++k) {
-            mn[k] = std::min(pos[k], std::min(pos[3 + k], pos[6 + k]));
-            mx[k] = std::max(pos[k], std::max(pos[3 + k], pos[6 + k]));
-            f.bmin[k] = mn[k]; f.bmax[k] = mx[k];
-        }
-        f.leaf = 1; f.triangles = 1;
-        out_nodes[0] = f;
-        *out_num_nodes = 1;
-        if (out_depth) *out_depth = 1;
-        cleanup();
-        return PTGPU_OK;
-    }
     LB_ALLOC(d_child, int2, n_int)
     LB_ALLOC(d_range, int2, n_int)
     LB_ALLOC(d_parent, int32_t, n_int)
@@ -1597,11 +1601,181 @@ extern "C" int ptgpu_bvh_build_lbvh(ptgpu_context* c, const float* pos, int32_t 
     LB_TRY(hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, st));
     LB_TRY(hipStreamSynchronize(st));
     if (h_size < 1 || h_size > 2 * n) { cleanup(); return fail(PTGPU_E_HIP, "BVH builder produced %d nodes for %d triangles", h_size, n); }
-    LB_TRY(hipMemcpy(out_nodes, d_nodes, (size_t)h_size * sizeof(ptgpu_flatnode), hipMemcpyDeviceToHost));
-    *out_num_nodes = h_size;
-    if (out_depth) *out_depth = h_out[0];
-    cleanup();
+    R.d_nodes = d_nodes; R.d_list = d_vals2; R.num_nodes = h_size; R.depth = h_out[0];
 #undef LB_TRY
 #undef LB_ALLOC
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_bvh_build_lbvh(ptgpu_context* c, const float* pos, int32_t num_tris, int32_t max_tris_in_leaf, ptgpu_flatnode* out_nodes,
+                                    int32_t* out_num_nodes, int32_t* out_list, int32_t* out_depth) {
+    if (!c || !out_num_nodes) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (num_tris < 0) return fail(PTGPU_E_INVALID, "num_tris < 0");
+    if (max_tris_in_leaf < 1) return fail(PTGPU_E_INVALID, "max_tris_in_leaf %d < 1", max_tris_in_leaf);
+    if (num_tris > 0 && (!pos || !out_nodes || !out_list)) return fail(PTGPU_E_INVALID, "NULL array");
+    *out_num_nodes = 0;
+    if (out_depth) *out_depth = 0;
+    if (num_tris == 0) return PTGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (num_tris == 1) {
+        for (int k = 0; k < 9; ++k)
+            if (!(std::fabs(pos[k]) <= 3.402823466e+38f)) return fail(PTGPU_E_INVALID, "a triangle has a vertex that is not finite");
+        ptgpu_flatnode f;
+        memset(&f, 0, sizeof f);
+        for (int k = 0; k < 3; ++k) {
+            f.bmin[k] = std::min(pos[k], std::min(pos[3 + k], pos[6 + k]));
+            f.bmax[k] = std::max(pos[k], std::max(pos[3 + k], pos[6 + k]));
+        }
+        f.leaf = 1; f.triangles = 1;
+        out_nodes[0] = f;
+        out_list[0] = 0;
+        *out_num_nodes = 1;
+        if (out_depth) *out_depth = 1;
+        return PTGPU_OK;
+    }
+    LbvhOnDevice R;
+    int rc = lbvh_build_on_device(c, pos, nullptr, num_tris, max_tris_in_leaf, R);
+    if (rc != PTGPU_OK) return rc;
+    hipError_t e = hipMemcpy(out_list, R.d_list, (size_t)num_tris * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_nodes, R.d_nodes, (size_t)R.num_nodes * sizeof(ptgpu_flatnode), hipMemcpyDeviceToHost);
+    *out_num_nodes = R.num_nodes;
+    if (out_depth) *out_depth = R.depth;
+    R.release();
+    if (e != hipSuccess) return fail(PTGPU_E_HIP, "copying the built tree to the host failed: %s", hipGetErrorString(e));
+    return PTGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scene straight from the device-built tree: the FlatNode array and the index list never visit the host.  The traversal records are
+// written by two kernels from the same fields build_scene() reads on the host, so the scene equals the one ptgpu_scene_create makes from
+// ptgpu_bvh_build_lbvh's output, record for record.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scene_inner_flags(const ptgpu_flatnode* __restrict__ nodes, int nn, int32_t* __restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nn) flag[i] = nodes[i].leaf ? 0 : 1;
+}
+// records = base + list_size records: interior node with interior index k at records[k], triangle record p at records[~p]
+__global__ __launch_bounds__(256) void k_scene_records(const ptgpu_flatnode* __restrict__ nodes, int nn, const int32_t* __restrict__ inner_index,
+                                                       const int32_t* __restrict__ list, const float* __restrict__ woop,
+                                                       const int32_t* __restrict__ mat_id, const ptgpu_material* __restrict__ materials,
+                                                       float4* __restrict__ records) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    const ptgpu_flatnode n = nodes[i];
+    if (n.leaf) {
+        for (int p = n.startIdx; p <= n.endIdx; ++p) {
+            const int32_t id = list[p], remaining = n.endIdx - p, mat = mat_id[id], atex = materials[mat].tex_alpha;
+            const float* w = woop + (size_t)id * 12;
+            float4* o = records + (ptrdiff_t)(~p) * 4;
+            o[0] = make_float4(w[0], w[1], w[2], w[3]);
+            o[1] = make_float4(w[4], w[5], w[6], w[7]);
+            o[2] = make_float4(w[8], w[9], w[10], w[11]);
+            o[3] = make_float4(__int_as_float(id), __int_as_float(remaining), __int_as_float(atex), __int_as_float(mat));
+        }
+    } else {
+        const ptgpu_flatnode L = nodes[i + 1], R = nodes[n.rightChild];
+        const int refL = L.leaf ? ~L.startIdx : inner_index[i + 1], refR = R.leaf ? ~R.startIdx : inner_index[n.rightChild];
+        float4* o = records + (ptrdiff_t)inner_index[i] * 4;
+        o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmax[0], L.bmax[1]);
+        o[1] = make_float4(R.bmin[0], R.bmin[1], R.bmax[0], R.bmax[1]);
+        o[2] = make_float4(L.bmin[2], L.bmax[2], R.bmin[2], R.bmax[2]);
+        o[3] = make_float4(__int_as_float(refL), __int_as_float(refR), __int_as_float(n.axis), 0.0f);
+    }
+}
+
+static int build_scene_lbvh(ptgpu_context* c, const ptgpu_scene_desc* d, int max_tris_in_leaf, ptgpu_scene* s) {
+    const int nt = d->num_tris;
+    s->num_tris = nt;
+    s->num_materials = d->num_materials;
+    s->num_textures = d->num_textures;
+    int rc = upload_shading_arrays(c, d, s);
+    if (rc != PTGPU_OK) return rc;
+    for (int i = 0; i < nt && !s->has_alpha; ++i)
+        if (d->materials[d->mat_id[i]].tex_alpha >= 0) s->has_alpha = true;
+    LbvhOnDevice R;
+    rc = lbvh_build_on_device(c, nullptr, s->d_pos, nt, max_tris_in_leaf, R);
+    if (rc != PTGPU_OK) return rc;
+    if (R.depth > 64) { R.release(); return fail(PTGPU_E_UNSUPPORTED, "tree depth %d exceeds 64 (the reference's traversal stack, RayTracer.cpp:190)", R.depth); }
+    const int nn = R.num_nodes;
+    hipStream_t st = c->stream;
+    int32_t *d_flag = nullptr, *d_index = nullptr;
+    float* d_woop = nullptr;
+    void* d_temp = nullptr;
+    auto fail_hip = [&](const char* what, hipError_t e) {
+        if (d_flag) hipFree(d_flag);
+        if (d_index) hipFree(d_index);
+        if (d_woop) hipFree(d_woop);
+        if (d_temp) hipFree(d_temp);
+        R.release();
+        return fail(PTGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&d_flag, (size_t)nn * sizeof(int32_t))) != hipSuccess) return fail_hip("hipMalloc", e);
+    if ((e = hipMalloc(&d_index, (size_t)nn * sizeof(int32_t))) != hipSuccess) return fail_hip("hipMalloc", e);
+    if ((e = hipMalloc(&d_woop, (size_t)nt * 12 * sizeof(float))) != hipSuccess) return fail_hip("hipMalloc", e);
+    if ((e = hipMemcpyAsync(d_woop, d->woop, (size_t)nt * 12 * sizeof(float), hipMemcpyHostToDevice, st)) != hipSuccess) return fail_hip("hipMemcpyAsync", e);
+    const unsigned nb = (unsigned)((nn + 255) / 256);
+    hipLaunchKernelGGL(k_scene_inner_flags, dim3(nb), dim3(256), 0, st, R.d_nodes, nn, d_flag);
+    size_t temp_bytes = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, temp_bytes, d_flag, d_index, 0, (size_t)nn, rocprim::plus<int32_t>(), st)) != hipSuccess) return fail_hip("exclusive_scan", e);
+    if ((e = hipMalloc(&d_temp, temp_bytes ? temp_bytes : 4)) != hipSuccess) return fail_hip("hipMalloc", e);
+    if ((e = rocprim::exclusive_scan(d_temp, temp_bytes, d_flag, d_index, 0, (size_t)nn, rocprim::plus<int32_t>(), st)) != hipSuccess) return fail_hip("exclusive_scan", e);
+    // interior count = index of the last node + its flag; the root's box and kind
+    int32_t last[2] = {0, 0};
+    ptgpu_flatnode root;
+    if ((e = hipMemcpyAsync(&last[0], d_index + (nn - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return fail_hip("hipMemcpyAsync", e);
+    if ((e = hipMemcpyAsync(&last[1], d_flag + (nn - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return fail_hip("hipMemcpyAsync", e);
+    if ((e = hipMemcpyAsync(&root, R.d_nodes, sizeof root, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail_hip("hipMemcpyAsync", e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail_hip("hipStreamSynchronize", e);
+    const int n_inner = last[0] + last[1], nl = nt;
+    if ((e = hipMalloc((void**)&s->d_records, ((size_t)nl + n_inner) * 64)) != hipSuccess) return fail_hip("hipMalloc", e);
+    s->trav.records = s->d_records + (size_t)nl * 4;
+    hipLaunchKernelGGL(k_scene_records, dim3(nb), dim3(256), 0, st, R.d_nodes, nn, d_index, R.d_list, d_woop, s->d_mat_id, s->d_materials,
+                       const_cast<float4*>(s->trav.records));
+    if ((e = hipGetLastError()) != hipSuccess) return fail_hip("k_scene_records", e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail_hip("hipStreamSynchronize", e);
+    for (int k = 0; k < 3; ++k) { s->trav.root_bmin[k] = root.bmin[k]; s->trav.root_bmax[k] = root.bmax[k]; }
+    s->trav.root_ref = root.leaf ? ~root.startIdx : 0;
+    s->trav.list_size = nl;
+    s->num_inner = n_inner;
+    s->depth = R.depth;
+    s->num_nodes_built = nn;
+    s->bytes[0] += (size_t)n_inner * 64;
+    s->bytes[1] += (size_t)nl * 64;
+    hipFree(d_flag); hipFree(d_index); hipFree(d_woop); hipFree(d_temp);
+    R.release();
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_scene_create_lbvh(ptgpu_context* c, const ptgpu_scene_desc* d, int32_t max_tris_in_leaf, ptgpu_scene** out, int32_t* out_num_nodes) {
+    if (!c || !d || !out) return fail(PTGPU_E_INVALID, "NULL argument");
+    if (d->num_nodes != 0 || d->list_size != 0 || d->nodes || d->list)
+        return fail(PTGPU_E_INVALID, "ptgpu_scene_create_lbvh builds the hierarchy itself: nodes / list of the description must be empty");
+    if (max_tris_in_leaf < 1) return fail(PTGPU_E_INVALID, "max_tris_in_leaf %d < 1", max_tris_in_leaf);
+    int rc = check_scene_arrays(d);
+    if (rc != PTGPU_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (d->num_tris < 2) {  // nothing to build on the device: the host path with the one-node (or empty) tree
+        ptgpu_scene_desc d2 = *d;
+        ptgpu_flatnode node;
+        int32_t list0 = 0, nn = 0, depth = 0;
+        rc = ptgpu_bvh_build_lbvh(c, d->pos, d->num_tris, max_tris_in_leaf, &node, &nn, &list0, &depth);
+        if (rc != PTGPU_OK) return rc;
+        d2.num_nodes = nn; d2.nodes = nn ? &node : nullptr; d2.list_size = nn ? 1 : 0; d2.list = nn ? &list0 : nullptr;
+        if (out_num_nodes) *out_num_nodes = nn;
+        return ptgpu_scene_create(c, &d2, out);
+    }
+    ptgpu_scene* s = new ptgpu_scene();
+    s->ctx = c;
+    rc = build_scene_lbvh(c, d, max_tris_in_leaf, s);
+    if (rc != PTGPU_OK) {
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        ptgpu_scene_destroy(s);
+        memcpy(g_err, keep, sizeof keep);
+        return rc;
+    }
+    if (out_num_nodes) *out_num_nodes = s->num_nodes_built;
+    *out = s;
     return PTGPU_OK;
 }

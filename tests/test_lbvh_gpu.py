@@ -128,3 +128,56 @@ def test_rejects_bad_input(gpu_ctx):
         gpu_ctx.bvh_build_lbvh(pos, 3)
     with pytest.raises(capi.PtgpuError):
         gpu_ctx.bvh_build_lbvh(np.zeros((4, 3, 3), np.float32), 0)
+
+
+@pytest.mark.parametrize("max_leaf", [1, 3])
+def test_scene_straight_from_the_device_built_tree(gpu_ctx, head, oracle, max_leaf):
+    """ptgpu_scene_create_lbvh (tree and traversal records never leave the device) against ptgpu_bvh_build_lbvh + ptgpu_scene_create
+    (the same tree through host arrays): same node count, depth and record bytes; hit records of closest-hit and any-hit rays and a
+    path-trace pass bit-identical -- and, through the host-array tree, equal to the oracle's."""
+    pos = head["mesh"]["pos"]
+    nodes, lst, depth = gpu_ctx.bvh_build_lbvh(pos, max_leaf)
+    sd = _scene_with(head["sd"], nodes, lst)
+    a = capi.Scene(gpu_ctx, sd)
+    b = capi.Scene(gpu_ctx, head["sd"], lbvh_max_tris_in_leaf=max_leaf)
+    try:
+        assert b.num_nodes_built == nodes.shape[0] and a.stats() == b.stats() and b.stats()["depth"] == depth
+        cam = scene.make_camera(width=160, height=96)
+        o, d = oracle.gen_primary(cam, 160, 96)
+        ga, gb = a.raycast(o, d, False), b.raycast(o, d, False)
+        c = oracle.raycast(sd, o, d, False, nthreads=8)
+        for k in ("id", "t", "u", "v"):
+            assert np.array_equal(ga[k].view(np.uint32), gb[k].view(np.uint32)) and np.array_equal(gb[k].view(np.uint32), c[k].view(np.uint32)), k
+        ro, rd = _rays(30000, 4, -0.6, 0.6, 1.5)
+        assert np.array_equal(a.raycast(ro, rd, True)["id"], b.raycast(ro, rd, True)["id"])
+        prm = scene.make_params(width=96, height=64, bounces=-1, num_aa_rays=2, sobol_block=True, pass_seed=8)
+        cam2, lights = scene.make_camera(width=96, height=64), [scene.make_light()]
+        assert np.array_equal(a.render_pass(prm, cam2, lights).view(np.uint32), b.render_pass(prm, cam2, lights).view(np.uint32))
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 1000])
+def test_scene_from_device_tree_small_inputs(gpu_ctx, oracle, n):
+    rng = np.random.RandomState(n + 3)
+    pos = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32)
+    nodes, lst, _ = gpu_ctx.bvh_build_lbvh(pos, 3)
+    sd = dict(pos=pos, nrm=scene.flat_normals(pos) if n else np.zeros((0, 3, 3), np.float32), uv=np.zeros((n, 3, 2), np.float32),
+              mat_id=np.zeros(n, np.int32), woop=oracle.woop_from_positions(pos) if n else np.zeros((0, 12), np.float32),
+              materials=[scene.make_material()], textures=[], nodes=nodes, list=lst)
+    a, b = capi.Scene(gpu_ctx, sd), capi.Scene(gpu_ctx, sd, lbvh_max_tris_in_leaf=3)
+    try:
+        o, d = _rays(3000, 2, -1.5, 1.5, 4.0)
+        ga, gb = a.raycast(o, d, False), b.raycast(o, d, False)
+        assert np.array_equal(ga["id"], gb["id"]) and np.array_equal(ga["t"].view(np.uint32), gb["t"].view(np.uint32))
+        assert (ga["id"] >= 0).any() or n < 2
+    finally:
+        a.close()
+        b.close()
+    with pytest.raises(capi.PtgpuError, match="builds the hierarchy itself"):
+        desc, keep = capi.make_scene_desc(sd)
+        if n == 0:
+            desc.num_nodes = 1  # an empty description has nothing to object to: force the check
+        h = capi._P()
+        capi._check(gpu_ctx.lib.ptgpu_scene_create_lbvh(gpu_ctx.handle, capi.C.byref(desc), 3, capi.C.byref(h), None))

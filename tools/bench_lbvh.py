@@ -48,6 +48,20 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     out = {"scene": which, "triangles": int(pos.shape[0]), "sah_build_s": t_sah, "lbvh_build_s_host_to_host": t_lbvh}
     ref_t = None
+    # scene creation: tree through host arrays (build + ptgpu_scene_create) against ptgpu_scene_create_lbvh (nothing leaves the device)
+    sd_l = dict(pos=pos, nrm=mesh["nrm"], uv=mesh["uv"], mat_id=mesh["mat_id"], woop=woop, materials=mesh["materials"], textures=[], nodes=lb[0], list=lb[1])
+    t0 = time.perf_counter()
+    sc_a = capi.Scene(ctx, sd_l)
+    ctx.sync()
+    out["scene_create_from_host_tree_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sc_b = capi.Scene(ctx, sd_l, lbvh_max_tris_in_leaf=3)
+    ctx.sync()
+    out["scene_create_lbvh_on_device_s"] = time.perf_counter() - t0
+    out["build_plus_create_through_host_s"] = t_lbvh + out["scene_create_from_host_tree_s"]
+    assert sc_a.stats() == sc_b.stats() and sc_b.num_nodes_built == lb[0].shape[0]
+    sc_a.close()
+    sc_b.close()
     for name, (nodes, lst, extra) in (("sah", sah), ("lbvh", lb)):
         sd = dict(pos=pos, nrm=mesh["nrm"], uv=mesh["uv"], mat_id=mesh["mat_id"], woop=woop, materials=mesh["materials"], textures=[], nodes=nodes, list=lst)
         sc = capi.Scene(ctx, sd)
