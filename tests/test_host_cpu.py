@@ -116,6 +116,26 @@ def test_md5_is_standard():
         assert hostapi.md5_hex(np.frombuffer(blob, np.uint8)) == hashlib.md5(blob).hexdigest()
 
 
+def test_md5_matches_the_reference_file(oracle):
+    """The host mirror's MD5 (pathtracer_amd/host/Md5.hpp; names the hierarchy cache like RayTracer::computeMD5, reference
+    src/RayTracer.cpp:57-66) against the reference's own src/Md5.c compiled where it lies (oracle/_ref, with the reference platform's
+    32-bit `long`: oracle/ref_md5_shim.c says why), and the mesh digest the host RayTracer computes against MD5Buffer over the same bytes."""
+    ref = oracle.ref()
+    if ref is None or not hasattr(ref, "MD5Buffer"):
+        pytest.skip("oracle/_ref not built (no /root/reference here); test_md5_is_standard covers the RFC vectors")
+    import ctypes as C
+    import struct
+    rng = np.random.RandomState(3)
+    blobs = [b"", b"abc", b"a" * 55, b"b" * 56, b"c" * 63, b"d" * 64, b"e" * 65, rng.bytes(100_003)]
+    blobs.append(np.ascontiguousarray(scene.load_ptmesh()["pos"], np.float32).tobytes())  # what computeMD5 hashes: the vertex positions
+    for blob in blobs:
+        buf = C.create_string_buffer(blob, max(len(blob), 1))
+        out = (C.c_uint * 4)()
+        ref.MD5Buffer(buf, C.c_size_t(len(blob)), out)
+        theirs = struct.pack("<4I", *out).hex()
+        assert theirs == hashlib.md5(blob).hexdigest() == hostapi.md5_hex(np.frombuffer(blob, np.uint8)), len(blob)
+
+
 def test_camera_pod_unprojects_pixel_centres(oracle):
     """invP from FW::CameraControls: the centre pixel's ray points along the camera's forward axis and starts in front
     of the eye; rays end on the far plane (segment semantics of reference src/PathTraceRenderer.cpp:251-266)."""
