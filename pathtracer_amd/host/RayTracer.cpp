@@ -39,12 +39,21 @@ void RayTracer::invalidateDeviceScene() {
 
 void RayTracer::constructHierarchy(std::vector<RTTriangle>& triangles, bool sahEnabled) {
     m_triangles = &triangles;
+    m_buildWithScene = 0;
     bvh = BVH(m_triangles, sahEnabled);
     invalidateDeviceScene();
 }
 
-void RayTracer::constructHierarchyOnDevice(std::vector<RTTriangle>& triangles, int maxTrisInLeaf) {
+void RayTracer::constructHierarchyOnDevice(std::vector<RTTriangle>& triangles, int maxTrisInLeaf, bool keepTree) {
     m_triangles = &triangles;
+    m_buildWithScene = 0;
+    if (!keepTree) {  // the tree is built when the device scene is (ptgpu_scene_create_lbvh) and never copied to the host
+        if (maxTrisInLeaf < 1) throw GpuError("constructHierarchyOnDevice: maxTrisInLeaf < 1");
+        m_buildWithScene = maxTrisInLeaf;
+        bvh = BVH();
+        invalidateDeviceScene();
+        return;
+    }
     const size_t n = triangles.size();
     std::vector<float> pos(n * 9);
     for (size_t i = 0; i < n; ++i)
@@ -74,6 +83,7 @@ template <class T> bool get(std::istream& s, T& v) { return (bool)s.read(reinter
 }  // namespace
 
 void RayTracer::saveHierarchy(const char* filename, const std::vector<RTTriangle>&) {
+    if (m_buildWithScene) throw GpuError("saveHierarchy: the hierarchy was built on the device without a host copy (constructHierarchyOnDevice keepTree = false)");
     std::ofstream f(filename, std::ios::binary);
     put(f, (int32_t)bvh.list.size());
     for (int32_t v : bvh.list) put(f, v);
@@ -89,6 +99,7 @@ void RayTracer::saveHierarchy(const char* filename, const std::vector<RTTriangle
 
 void RayTracer::loadHierarchy(const char* filename, std::vector<RTTriangle>& triangles) {
     m_triangles = &triangles;
+    m_buildWithScene = 0;
     std::ifstream f(filename, std::ios::binary);
     if (!f) throw GpuError(std::string("loadHierarchy: cannot open ") + filename);
     f.seekg(0, std::ios::end);
@@ -166,6 +177,10 @@ ptgpu_scene* RayTracer::deviceScene() const {
     d.pos = pos.data(); d.nrm = nrm.data(); d.uv = uv.data(); d.mat_id = matId.data(); d.woop = woop.data();
     d.num_materials = (int32_t)pm.size(); d.materials = pm.data();
     d.num_textures = (int32_t)texs.size(); d.textures = texs.data();
+    if (m_buildWithScene) {
+        PT_GPU(ptgpu_scene_create_lbvh(GpuDevice::instance().ctx(), &d, m_buildWithScene, &m_scene, nullptr));
+        return m_scene;
+    }
     d.num_nodes = (int32_t)bvh.nodes.size();
     d.nodes = reinterpret_cast<const ptgpu_flatnode*>(bvh.nodes.data());  // same 64-byte layout, uploaded as-is
     d.list_size = (int32_t)bvh.list.size(); d.list = bvh.list.data();

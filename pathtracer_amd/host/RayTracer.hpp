@@ -32,7 +32,9 @@ public:
     void constructHierarchy(std::vector<RTTriangle>& triangles, bool sahEnabled);
     // Not in the reference: the linear BVH built on the device (ptgpu_bvh_build_lbvh), installed as bvh.nodes / bvh.list like a tree
     // from the CPU builders.  Hit records can differ from the SAH tree's at exact ties (see include/ptgpu.h).
-    void constructHierarchyOnDevice(std::vector<RTTriangle>& triangles, int maxTrisInLeaf = 3);
+    // keepTree = false: the tree is built together with the device scene (ptgpu_scene_create_lbvh) and never copied to the host -- bvh stays
+    // empty and saveHierarchy throws; for scenes rebuilt every frame.
+    void constructHierarchyOnDevice(std::vector<RTTriangle>& triangles, int maxTrisInLeaf = 3, bool keepTree = true);
     void loadHierarchy(const char* filename, std::vector<RTTriangle>& triangles);
     void saveHierarchy(const char* filename, const std::vector<RTTriangle>& triangles);
 
@@ -52,6 +54,7 @@ public:
 private:
     mutable std::atomic<long long> m_rayCount{0};
     mutable ptgpu_scene* m_scene = nullptr;
+    int m_buildWithScene = 0;  // > 0: maxTrisInLeaf of a hierarchy that deviceScene() builds on the device
 };
 
 }  // namespace FW

@@ -198,8 +198,8 @@ int pth_rt_material(void* h, int i, char name64[64], float out_f[8], int32_t out
 int pth_rt_save_hierarchy(void* h, const char* path) { return guarded([&] { auto* b = static_cast<TracerBox*>(h); b->rt.saveHierarchy(path, b->tris); }); }
 int pth_rt_load_hierarchy(void* h, const char* path) { return guarded([&] { auto* b = static_cast<TracerBox*>(h); b->rt.loadHierarchy(path, b->tris); }); }
 // RayTracer::constructHierarchyOnDevice (not in the reference): replace the hierarchy by the device-built linear BVH
-int pth_rt_construct_on_device(void* h, int max_tris_in_leaf) {
-    return guarded([&] { auto* b = static_cast<TracerBox*>(h); b->rt.constructHierarchyOnDevice(b->tris, max_tris_in_leaf); });
+int pth_rt_construct_on_device(void* h, int max_tris_in_leaf, int keep_tree) {
+    return guarded([&] { auto* b = static_cast<TracerBox*>(h); b->rt.constructHierarchyOnDevice(b->tris, max_tris_in_leaf, keep_tree != 0); });
 }
 int pth_rt_mesh_md5(void* h, char out33[33]) {
     TracerBox* b = static_cast<TracerBox*>(h);

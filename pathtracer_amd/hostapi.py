@@ -52,7 +52,7 @@ def lib():
         L.pth_rt_material.argtypes = [_P, C.c_int, _P, _P, _P]
         L.pth_rt_save_hierarchy.argtypes = [_P, C.c_char_p]
         L.pth_rt_load_hierarchy.argtypes = [_P, C.c_char_p]
-        L.pth_rt_construct_on_device.argtypes = [_P, C.c_int]
+        L.pth_rt_construct_on_device.argtypes = [_P, C.c_int, C.c_int]
         L.pth_rt_mesh_md5.argtypes = [_P, _P]
         L.pth_rt_raycast.argtypes = [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P]
         L.pth_pt_render.argtypes = [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int, C.POINTER(Params), C.c_int,
@@ -192,9 +192,10 @@ class HostRayTracer:
     def load_hierarchy(self, path):
         _check(lib().pth_rt_load_hierarchy(self.h, path.encode()))
 
-    def construct_hierarchy_on_device(self, max_tris_in_leaf=3):
-        """RayTracer::constructHierarchyOnDevice: the device-built linear BVH replaces the current hierarchy."""
-        _check(lib().pth_rt_construct_on_device(self.h, int(max_tris_in_leaf)))
+    def construct_hierarchy_on_device(self, max_tris_in_leaf=3, keep_tree=True):
+        """RayTracer::constructHierarchyOnDevice: the device-built linear BVH replaces the current hierarchy.  keep_tree=False: the tree is
+        built together with the device scene and never copied to the host (no nodes / list to read back, save_hierarchy raises)."""
+        _check(lib().pth_rt_construct_on_device(self.h, int(max_tris_in_leaf), int(bool(keep_tree))))
         c = np.zeros(4, np.int32)
         lib().pth_rt_counts(self.h, c.ctypes.data)
         self.num_tris, self.num_nodes, self.list_size, self.depth_field = (int(x) for x in c)

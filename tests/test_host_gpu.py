@@ -114,6 +114,15 @@ def test_host_device_built_hierarchy(head, oracle, tmp_path):
         for f in ("bmin", "bmax", "startIdx", "endIdx", "rightChild", "leaf", "axis"):
             assert np.array_equal(n2[f], nodes[f]), f
         assert np.array_equal(l2, lst)
+        # keepTree = false: the same tree built together with the device scene (ptgpu_scene_create_lbvh), nothing copied to the host
+        want = {occ: rt.raycast(o, d, occ) for occ in (False, True)}
+        rt.construct_hierarchy_on_device(3, keep_tree=False)
+        assert rt.num_nodes == 0 and rt.list_size == 0
+        for occ in (False, True):
+            g = rt.raycast(o, d, occ)
+            assert np.array_equal(g["id"], want[occ]["id"]) and np.array_equal(g["t"].view(np.uint32), want[occ]["t"].view(np.uint32))
+        with pytest.raises(hostapi.HostError, match="without a host copy"):
+            rt.save_hierarchy(path)
     finally:
         rt.close()
 
