@@ -2,7 +2,8 @@
 """Short, fixed launch sequence for rocprofv3 (kernel trace or one --pmc pass per run):
   5 x configs[1] frame as bench.py's step runs it (ptgpu_trace_frame_dev, one launch) and 5 x as four launches (gen_primary, raycast
   closest, gen_shadow, raycast any-hit) on head.obj 1920x1080, then
-  1 x path-trace pass of the configs[2] frame at 16 spp (Gaussian AA, textures + normal maps, RR).
+  1 x path-trace pass of the configs[2] frame at 16 spp (Gaussian AA, textures + normal maps, RR); with PROFILE_POOLED=1 in the
+  environment the same pass once more through the pooled integrator.
 Usage on the GPU box:   rocprofv3 --kernel-trace --stats ... -- python3 tools/profile_kernels.py
                         rocprofv3 --pmc FETCH_SIZE ... -- python3 tools/profile_kernels.py"""
 import os
@@ -51,6 +52,11 @@ def main():
         sct.render_pass_dev(prm, cam, [light], accum.data_ptr())
         torch.cuda.synchronize()
         print("path-trace pass: %d samples, %d rays" % (n * spp, ctx.counters()["rays"]))
+        if os.environ.get("PROFILE_POOLED", "0") != "0":  # the same pass through the experimental pooled integrator (k_integrate_pool)
+            os.environ["PTGPU_PT_POOL"] = "1"
+            sct.render_pass_dev(prm, cam, [light], accum.data_ptr())
+            torch.cuda.synchronize()
+            os.environ["PTGPU_PT_POOL"] = "0"
         sct.close()
     ctx.close()
 
