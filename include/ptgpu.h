@@ -211,6 +211,15 @@ int ptgpu_render_pass_dev(ptgpu_scene* scene, const ptgpu_params* params, const 
                           int32_t num_lights, int32_t block_begin, int32_t block_end, int32_t block_stride, float* d_accum);
 int ptgpu_render_pass(ptgpu_scene* scene, const ptgpu_params* params, const ptgpu_camera* cam, const ptgpu_light* lights,
                       int32_t num_lights, int32_t block_begin, int32_t block_end, int32_t block_stride, float* accum);
+/* PathTraceRenderer::stop() while a pass is running: the reference's workers poll m_bForceExit before every sample and return
+ * (src/PathTraceRenderer.cpp:709,736), and stop() waits only for that (:918-930).  ptgpu_cancel cancels every render pass enqueued on the
+ * context so far: the integrator's persistent waves poll a cancel word when they draw a new chunk of samples and draw no more, the samples
+ * in flight run to their end, and a batch of blocks whose samples are not all there is NOT accumulated -- so d_accum is left holding whole
+ * batches only (finite, a valid partial image) and the stream drains within milliseconds; ptgpu_sync / ptgpu_query then report
+ * completion as usual.  Passes enqueued after the call are not affected.  Makes no HIP call: callable from any thread at any time,
+ * in particular while another thread is blocked in ptgpu_sync or in the host-pointer ptgpu_render_pass. */
+int ptgpu_cancel(ptgpu_context* ctx);
+
 /* ---- the reference's static per-sample functions (src/PathTraceRenderer.hpp:97-102), evaluated by the same device code the render pass runs.
  * ptgpu_trace_samples[_dev]: Vec3f tracePath(x, y, ctx, samplerBase, R, ...) (src/PathTraceRenderer.cpp:236-551), or traceWhitted
  * (:553-660) when params->whitted, for n arbitrary samples: xy [n][2] clip-space position, sampler_base [n] Sobol index base,
@@ -231,6 +240,12 @@ int ptgpu_texture_parameters_batch(ptgpu_scene* scene, const ptgpu_params* param
  * rng_state [n][2] (key, counter).  HOST arrays; out [n][2] = chosen light, counter after the call (one draw when num_lights > 1). */
 int ptgpu_light_to_sample_batch(ptgpu_context* ctx, const ptgpu_light* lights, int32_t num_lights, int64_t n, const float* pos,
                                 const uint32_t* rng_state, int32_t* out_index_and_counter);
+
+/* float sobol::sample(index, dimension) (src/sobol.h:39-49; scramble 0, as every call site passes) for n (index, dimension < 1024) pairs,
+ * evaluated by the device functions the kernels draw their Sobol points with (byte-indexed pair table for the low 24 index bits, the
+ * bit loop above them).  HOST arrays.  Exists so that the device's Sobol values can be compared word for word with the reference's own
+ * sobol.cpp. */
+int ptgpu_sobol_sample_batch(ptgpu_context* ctx, int64_t n, const uint64_t* index, const uint32_t* dimension, float* out);
 
 /* PathTraceRenderer::updatePicture (src/PathTraceRenderer.cpp:855-871): out = (pow(rgb / w, 1/2.2), w / w) per pixel, w == 0
  * pixels pass through undivided.  Both pointers are DEVICE pointers, [height][width][4] floats. */

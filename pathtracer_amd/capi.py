@@ -98,10 +98,12 @@ SIGNATURES = [
     ("ptgpu_gen_shadow_dev", C.c_int, [_P, C.POINTER(Light), C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("ptgpu_render_pass_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("ptgpu_render_pass", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("ptgpu_cancel", C.c_int, [_P]),
     ("ptgpu_trace_samples_dev", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     ("ptgpu_trace_samples", C.c_int, [_P, C.POINTER(Params), C.POINTER(Camera), _P, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     ("ptgpu_texture_parameters_batch", C.c_int, [_P, C.POINTER(Params), C.c_int64, _P, _P, _P, _P]),
     ("ptgpu_light_to_sample_batch", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    ("ptgpu_sobol_sample_batch", C.c_int, [_P, C.c_int64, _P, _P, _P]),
     ("ptgpu_resolve_dev", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     ("ptgpu_spill_status", C.c_int, [_P, C.POINTER(C.c_uint64 * 3)]),
     ("ptgpu_comm_create_id", C.c_int, [_P]),
@@ -181,6 +183,10 @@ class Context:
     def sync(self):
         _check(self.lib.ptgpu_sync(self.handle))
 
+    def cancel(self):
+        """Cancel every render pass enqueued so far (PathTraceRenderer::stop() mid-pass)."""
+        _check(self.lib.ptgpu_cancel(self.handle))
+
     def malloc(self, nbytes):
         p = _P()
         _check(self.lib.ptgpu_malloc(self.handle, nbytes, C.byref(p)))
@@ -247,6 +253,13 @@ class Context:
         _check(self.lib.ptgpu_light_to_sample_batch(self.handle, C.cast(larr, _P), len(lights), pos.shape[0], pos.ctypes.data, rng.ctypes.data,
                                                     out.ctypes.data))
         return out[:, 0].copy(), out[:, 1].copy()
+
+    def sobol_sample(self, index, dimension):
+        """sobol::sample(index, dimension) on the device for arrays of (index uint64, dimension uint32) -> float32."""
+        idx, dim = np.ascontiguousarray(index, np.uint64), np.ascontiguousarray(dimension, np.uint32)
+        out = np.empty(idx.shape[0], np.float32)
+        _check(self.lib.ptgpu_sobol_sample_batch(self.handle, idx.shape[0], idx.ctypes.data, dim.ctypes.data, out.ctypes.data))
+        return out
 
     def resolve_dev(self, d_accum, width, height, d_out):
         _check(self.lib.ptgpu_resolve_dev(self.handle, d_accum, width, height, d_out))

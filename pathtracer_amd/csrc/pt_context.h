@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <vector>
@@ -69,6 +70,11 @@ struct ptgpu_context {
     size_t stage_bytes = 0;
     unsigned char* scratch = nullptr;  // THIS device's address of the file-scope scratch array (ptgpu_raycast_batch_dev_noalloc)
     ptgpu_comm* comm = nullptr;        // tile-gather communicator (ptgpu_comm_init), owned
+    // ptgpu_cancel: one word of pinned, host-coherent memory = number of the last cancelled render pass; the kernels of pass number
+    // pass_epoch read it through d_cancel.  Written by the host with a plain atomic store: no HIP call, any thread.
+    uint32_t* h_cancel = nullptr;
+    uint32_t* d_cancel = nullptr;
+    std::atomic<uint32_t> pass_epoch{0};
 };
 
 // pt_multigpu.hip

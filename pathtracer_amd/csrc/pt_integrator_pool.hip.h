@@ -77,12 +77,17 @@ struct PoolCtl {
     uint32_t head[3], tail[3];
     uint32_t retired;  // slots that found the sample range exhausted
     uint32_t cursor;   // samples this workgroup has drawn
-    uint32_t abort;    // a wave saw no progress for POOL_WATCHDOG_TICKS: every wave of the workgroup leaves (the launch's result is invalid;
-                       // counters[CTR_POOL_ABORT] tells the host).  Every wait in this file ends on it, so a launch cannot hang the device.
+    uint32_t abort;    // a wave saw no progress for the watchdog's ticks: every wave of the workgroup leaves (the launch's result is invalid;
+                       // counters[CTR_POOL_ABORT] tells the host).  Every wait in this file ends on it AND carries its own time bound (the
+                       // per-lane ring waits raise it themselves), so a launch cannot hang the device.
+    uint32_t watchdog_log2;        // the bound, as a power of two of s_memtime ticks (knobs bits 16-21; POOL_WATCHDOG_LOG2 unless a test lowers it)
+    unsigned long long* counters;  // the context's counter words, for the waits that have no other way to report
 };
-constexpr long long POOL_WATCHDOG_TICKS = 1ll << 31;
+constexpr int POOL_WATCHDOG_LOG2 = 31;
+constexpr long long POOL_WATCHDOG_TICKS = 1ll << POOL_WATCHDOG_LOG2;
 constexpr int CTR_POOL_ABORT = 7;
 __device__ __forceinline__ bool pool_aborted(const PoolCtl* ctl) { return *(const volatile uint32_t*)&ctl->abort != 0u; }
+__device__ __forceinline__ long long pool_watchdog_ticks(const PoolCtl* ctl) { return 1ll << (*(const volatile uint32_t*)&ctl->watchdog_log2 & 63u); }
 // called by a wave that has waited too long: raises the flag and leaves the queue state where the host can read it (diagnostic words 8..)
 __device__ __forceinline__ void pool_raise_abort(PoolCtl* ctl, unsigned long long* counters, int where) {
     if ((threadIdx.x & 63) == 0 && atomicExch(&ctl->abort, 1u) == 0u) {
@@ -94,6 +99,29 @@ __device__ __forceinline__ void pool_raise_abort(PoolCtl* ctl, unsigned long lon
             counters[17] = ctl->retired; counters[18] = ctl->cursor;
         }
     }
+}
+
+// the same from ONE lane that has waited too long inside a ring wait (whichever lane it is)
+__device__ __forceinline__ void pool_raise_abort_lane(PoolCtl* ctl, int where) {
+    if (atomicExch(&ctl->abort, 1u) == 0u) {
+        unsigned long long* counters = ctl->counters;
+        atomicAdd(&counters[CTR_POOL_ABORT], 1ull);
+        if (atomicAdd(&counters[8], 1ull) == 0ull) {
+            counters[9] = (unsigned long long)blockIdx.x | ((unsigned long long)(threadIdx.x >> 6) << 32);
+            counters[10] = (unsigned long long)where;
+        }
+    }
+}
+// wait until ring place e is empty (want_empty) or filled; gives up on the abort flag or after the watchdog's ticks
+__device__ __forceinline__ uint16_t pool_ring_wait(PoolCtl* ctl, volatile uint16_t* e, bool want_empty, int where) {
+    uint16_t v = *e;
+    if ((v == 0) == want_empty) return v;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime(), bound = pool_watchdog_ticks(ctl);
+    while (((v = *e) == 0) != want_empty && !pool_aborted(ctl)) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((long long)__builtin_amdgcn_s_memtime() - t0 > bound) { pool_raise_abort_lane(ctl, where); break; }
+    }
+    return v;
 }
 
 constexpr size_t pool_lds_bytes() {
@@ -117,7 +145,7 @@ __device__ __forceinline__ void pool_push(PoolCtl* ctl, uint16_t* ring, int q, b
     base = (uint32_t)__shfl((int)base, leader);
     if (pred) {
         volatile uint16_t* e = ring + q * POOL_QCAP + ((base + (uint32_t)rank) & (POOL_QCAP - 1));
-        while (*e != 0 && !pool_aborted(ctl)) __builtin_amdgcn_s_sleep(1);  // a reader that claimed this place a lap ago has not emptied it yet
+        pool_ring_wait(ctl, e, true, 6);  // a reader that claimed this place a lap ago has not emptied it yet
         *e = pool_entry(slot, base + (uint32_t)rank);
     }
 }
@@ -144,10 +172,9 @@ __device__ __forceinline__ int pool_pop(PoolCtl* ctl, uint16_t* ring, int q, uns
     const int rank = __popcll(want & ((1ull << lane) - 1ull));
     if (((want >> lane) & 1ull) && rank < n) {
         volatile uint16_t* e = ring + q * POOL_QCAP + ((h + (uint32_t)rank) & (POOL_QCAP - 1));
-        uint16_t v;
-        while ((v = *e) == 0 && !pool_aborted(ctl)) __builtin_amdgcn_s_sleep(1);  // the writer has reserved this place and is about to fill it
+        const uint16_t v = pool_ring_wait(ctl, e, false, 7);  // the writer has reserved this place and is about to fill it
         *e = 0;
-        slot = (int)(v & 1023u) - 1;
+        slot = (int)(v & 1023u) - 1;  // -1 if the wait was given up: the lane holds no slot, and every wave is leaving
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return n;
@@ -168,7 +195,7 @@ __device__ __forceinline__ void pool_push2(PoolCtl* ctl, uint16_t* ring, int qa,
     if (pa || pb) {
         const uint32_t pos = pa ? base_a + (uint32_t)__popcll(ma & below) : base_b + (uint32_t)__popcll(mb & below);
         volatile uint16_t* e = ring + (pa ? qa : qb) * POOL_QCAP + (pos & (POOL_QCAP - 1));
-        while (*e != 0 && !pool_aborted(ctl)) __builtin_amdgcn_s_sleep(1);
+        pool_ring_wait(ctl, e, true, 8);
         *e = pool_entry(slot, pos);
     }
 }
@@ -201,7 +228,7 @@ __device__ __forceinline__ void pool_trace_wave(const TravScene& TS, const ptgpu
 #endif
         if ((++iteration & 255u) == 0u) {  // a ray that never ends (it cannot, on a validated tree) must not hold the device either
             if (__builtin_amdgcn_readfirstlane((int)pool_aborted(ctl))) break;
-            if ((long long)__builtin_amdgcn_s_memtime() - t_progress > POOL_WATCHDOG_TICKS) { pool_raise_abort(ctl, counters, 3); break; }
+            if ((long long)__builtin_amdgcn_s_memtime() - t_progress > pool_watchdog_ticks(ctl)) { pool_raise_abort(ctl, counters, 3); break; }
         }
         const unsigned long long alive_mask = __ballot(tr.alive);
         const int n_fin = __popcll(__ballot(slot >= 0 && !tr.alive));
@@ -216,7 +243,7 @@ __device__ __forceinline__ void pool_trace_wave(const TravScene& TS, const ptgpu
             // and the rays they wait for come from that shade wave
             if (__builtin_amdgcn_readfirstlane(vload(&ctl->retired)) >= (uint32_t)POOL_SLOTS) break;
             if (__builtin_amdgcn_readfirstlane((int)pool_aborted(ctl))) break;
-            if ((long long)__builtin_amdgcn_s_memtime() - t_progress > POOL_WATCHDOG_TICKS) { pool_raise_abort(ctl, counters, 1); break; }
+            if ((long long)__builtin_amdgcn_s_memtime() - t_progress > pool_watchdog_ticks(ctl)) { pool_raise_abort(ctl, counters, 1); break; }
             const long long ps_t1 = PS_NOW();
             __builtin_amdgcn_s_sleep(32);
             PS_ADD(4, PS_NOW() - ps_t1); PS_ADD(5, 1);
@@ -421,7 +448,7 @@ __device__ __forceinline__ void pool_shade_wave(const TravScene& TS, const Shade
         }
         if (job < 0) {
             if (__builtin_amdgcn_readfirstlane((int)pool_aborted(ctl))) break;
-            if ((long long)__builtin_amdgcn_s_memtime() - t_progress > POOL_WATCHDOG_TICKS) { pool_raise_abort(ctl, counters, 2); break; }
+            if ((long long)__builtin_amdgcn_s_memtime() - t_progress > pool_watchdog_ticks(ctl)) { pool_raise_abort(ctl, counters, 2); break; }
             __builtin_amdgcn_s_sleep(8); PS_ADD(0, PS_NOW() - ps_t0); PS_ADD(1, 1);
             continue;
         }
@@ -531,6 +558,7 @@ __device__ __forceinline__ void pool_shade_wave(const TravScene& TS, const Shade
             // new samples for the idle slots
             const unsigned long long need = __ballot(slot >= 0 && ps.stage == ST_IDLE);
             if (need != 0ull) {
+                const bool cancelled = pass_cancelled(pd);  // ptgpu_cancel: the slots retire as if the range were exhausted
                 uint32_t cbase = 0;
                 if (lane == 0) cbase = atomicAdd(&ctl->cursor, (uint32_t)__popcll(need));
                 cbase = (uint32_t)__shfl((int)cbase, 0);
@@ -541,7 +569,7 @@ __device__ __forceinline__ void pool_shade_wave(const TravScene& TS, const Shade
                     const uint32_t r = cc / POOL_CHUNK, off = cc % POOL_CHUNK, G = gridDim.x;
                     const unsigned long long chunk = (unsigned long long)r * G + (blockIdx.x + (r % G) * 997u) % G;
                     const unsigned long long sid64 = chunk * POOL_CHUNK + off;
-                    if (sid64 >= (unsigned long long)total) {
+                    if (sid64 >= (unsigned long long)total || cancelled) {
                         ps.stage = ST_FIN;  // (transient) retired: every later draw of this workgroup lies beyond the range too
                     } else {
                         int n_width = prm.width, n_height = prm.height, n_spb = pd.samples_per_block, n_blocks_x = pd.blocks_x, n_aa = prm.num_aa_rays;
@@ -666,6 +694,8 @@ __device__ __forceinline__ void integrate_pool(const TravScene& TS, const ShadeS
         ctl->retired = 0u;
         ctl->cursor = 0u;
         ctl->abort = 0u;
+        ctl->watchdog_log2 = (uint32_t)((knobs >> 16) & 63);
+        ctl->counters = counters;
     }
     __syncthreads();
     if (wave < POOL_TW) {

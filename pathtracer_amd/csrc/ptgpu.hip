@@ -100,6 +100,9 @@ static int init_context(ptgpu_context* c, const hipDeviceProp_t& prop) {
     hipLaunchKernelGGL(k_build_sobol_pairs, dim3((entries + 255) / 256), dim3(256), 0, c->stream, c->d_sobol_pairs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipHostMalloc((void**)&c->h_cancel, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *c->h_cancel = 0u;
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->d_cancel, c->h_cancel, 0));
     return noalloc_scratch_address(&c->scratch);  // device `device` is current
 }
 
@@ -141,6 +144,7 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     if (c->d_stack_ovf) hipFree(c->d_stack_ovf);
     if (c->d_defer) hipFree(c->d_defer);
     if (c->d_sobol_pairs) hipFree(c->d_sobol_pairs);
+    if (c->h_cancel) hipHostFree(c->h_cancel);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return PTGPU_OK;
@@ -165,6 +169,15 @@ extern "C" int ptgpu_query(ptgpu_context* c, int* out_done) {
     *out_done = (e == hipSuccess) ? 1 : 0;
     return PTGPU_OK;
 }
+// Cancels every render pass enqueued on the context so far (ptgpu_render_pass[_dev] calls that have returned or are running in another
+// thread): their persistent waves stop drawing samples at their next poll, batches that were not complete are not accumulated, and the
+// stream drains within milliseconds.  Passes enqueued afterwards are not affected.  No HIP call: safe from any thread at any time.
+extern "C" int ptgpu_cancel(ptgpu_context* c) {
+    if (!c || !c->h_cancel) return fail(PTGPU_E_INVALID, "ctx is NULL or not initialised");
+    __atomic_store_n(c->h_cancel, c->pass_epoch.load(std::memory_order_acquire), __ATOMIC_RELEASE);
+    return PTGPU_OK;
+}
+
 extern "C" int ptgpu_malloc(ptgpu_context* c, uint64_t bytes, void** out) {
     if (!c || !out) return fail(PTGPU_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -591,8 +604,9 @@ static int launch_rc_persist(ptgpu_scene* s, RcWorkspace& ws, const ptd::TravSce
     }
     long long resident = (long long)c->num_cu * per_cu * env_int("PTGPU_RAYCAST_OVERSUB", 1);
     if (blocks > resident) blocks = resident;
-    if (!ws.grow && blocks > ws.max_persist_blocks) blocks = ws.max_persist_blocks;
     if (OVF) {
+        // fixed workspace: the grid is clamped to the waves its overflow region holds (variants without overflow stacks need no clamp)
+        if (!ws.grow && blocks > ws.max_persist_blocks) blocks = ws.max_persist_blocks;
         int rc = ws_stack_overflow(ws, (size_t)blocks * (RC_BLOCK / 64) * ptd::stack_overflow_bytes_per_wave<NLDS>());
         if (rc != PTGPU_OK) return rc;
     }
@@ -876,6 +890,8 @@ extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, co
     ptd::TravScene trav = s->trav;
     trav.alpha_on = 0;
     const int tw = env_int("PTGPU_FRAME_TILE_W", 8);
+    if (tw != 4 && tw != 8 && tw != 16 && tw != 32 && tw != 64)  // the instantiated set: the grid below must describe the kernel that runs
+        return fail(PTGPU_E_INVALID, "PTGPU_FRAME_TILE_W=%d: the frame kernel is built for tiles 4, 8, 16, 32 or 64 pixels wide", tw);
     const int th = 64 / tw;
     const int tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
     const dim3 grid((unsigned)(tiles_x * tiles_y));
@@ -970,6 +986,7 @@ __global__ __launch_bounds__(256) void k_accum_sobol(ptgpu_params prm, ptd::Pass
                                                      float4* __restrict__ spill, unsigned long long* counters) {
     __shared__ float4 acc[1024];
     __shared__ int owner[1024];
+    if (ptd::pass_cancelled(pd)) return;  // the batch's radiance may be incomplete: none of it is added (workgroup-uniform)
     const int jj = blockIdx.x, tid = threadIdx.x;
     int bx, by, bw, bh;
     block_rect(prm, pd, jj, bx, by, bw, bh);
@@ -1056,6 +1073,7 @@ __global__ void k_apply_spill(ptgpu_params prm, TileOwner own, const float4* __r
 }
 
 __global__ __launch_bounds__(256) void k_accum_gauss(ptgpu_params prm, ptd::PassDesc pd, const float4* __restrict__ rad, float* __restrict__ accum) {
+    if (ptd::pass_cancelled(pd)) return;  // as in k_accum_sobol
     const int jj = blockIdx.x;
     int bx, by, bw, bh;
     block_rect(prm, pd, jj, bx, by, bw, bh);
@@ -1178,7 +1196,7 @@ static int launch_integrate_pool(ptgpu_scene* s, const ptd::TravScene& trav, con
     int rc = ensure_stack_overflow(c, ovf_bytes + (size_t)blocks * ptd::pool_cold_bytes_per_group());
     if (rc != PTGPU_OK) return rc;
     hipLaunchKernelGGL((k_integrate_pool<ALPHA>), dim3((unsigned)blocks), dim3(ptd::POOL_THREADS), lds, c->stream, trav, ss, *prm, *cam, c->d_lights, pd, c->d_rad,
-                       c->d_counters, c->d_stack_ovf, reinterpret_cast<ptd::PoolCold*>(reinterpret_cast<unsigned char*>(c->d_stack_ovf) + ovf_bytes), env_int("PTGPU_POOL_REFILL", 16) | (env_int("PTGPU_POOL_LOW", 32) << 8));
+                       c->d_counters, c->d_stack_ovf, reinterpret_cast<ptd::PoolCold*>(reinterpret_cast<unsigned char*>(c->d_stack_ovf) + ovf_bytes), env_int("PTGPU_POOL_REFILL", 16) | (env_int("PTGPU_POOL_LOW", 32) << 8) | ((env_int("PTGPU_POOL_WATCHDOG_LOG2", ptd::POOL_WATCHDOG_LOG2) & 63) << 16));
     return PTGPU_OK;
 }
 
@@ -1202,7 +1220,8 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     // spill list and dropped-sample count are per pass (all batches of this call append to one list, applied after the last block sum)
     if (prm->sobol_block) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + CTR_SPILL, 2);
     const bool pooled = env_int("PTGPU_PT_POOL", 0) != 0;  // the pooled form of the integrator (csrc/pt_integrator_pool.hip.h), off unless asked for
-    if (pooled) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + ptd::CTR_POOL_ABORT, 1);
+    // the pooled integrator's abort word is per pass too, whichever integrator this pass runs (ptgpu_spill_status reads it after every pass)
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + ptd::CTR_POOL_ABORT, 1);
     const int count = (block_end - block_begin + block_stride - 1) / block_stride;  // blocks of this call
     const long long spb = 1024LL * prm->num_aa_rays;
     // samples per integrator launch: every launch ends with a tail of waves draining, so few, large launches (the radiance buffer is
@@ -1226,6 +1245,7 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     ss.pos = s->d_pos; ss.nrm = s->d_nrm; ss.uv = s->d_uv; ss.materials = s->d_materials; ss.textures = s->d_textures;
     ss.sobol_pairs = c->d_sobol_pairs;
     const int stack_need = s->depth - 1, nlds = env_int("PTGPU_PT_NLDS", 16);
+    const uint32_t epoch = c->pass_epoch.fetch_add(1u, std::memory_order_acq_rel) + 1u;  // this pass's number, for ptgpu_cancel
     for (int j0 = 0; j0 < count; j0 += (int)batch_blocks) {
         ptd::PassDesc pd;
         pd.block_begin = block_begin; pd.block_stride = block_stride; pd.j0 = j0;
@@ -1233,6 +1253,7 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
         pd.blocks_x = blocks_x; pd.samples_per_block = (int32_t)spb; pd.num_lights = num_lights;
         pd.inv_prob = 1.0f / prm->termination_prob;
         pd.ext_xy = nullptr; pd.ext_base = nullptr; pd.ext_rng = nullptr; pd.num_ext = 0;
+        pd.cancel = c->d_cancel; pd.epoch = epoch;
         // the alpha-cutout code is only compiled into the variants a scene with alpha maps takes (fewer registers for all others)
 #define PT_LAUNCH(COUNT_, NLDS_, OVF_) (trav.alpha_on ? launch_integrate<COUNT_, NLDS_, OVF_, true>(s, trav, ss, prm, cam, pd) \
                                                       : launch_integrate<COUNT_, NLDS_, OVF_, false>(s, trav, ss, prm, cam, pd))
@@ -1269,8 +1290,8 @@ extern "C" int ptgpu_spill_status(ptgpu_context* c, uint64_t out[3]) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[CTR_FOREIGN - CTR_SPILL] < (unsigned long long)FOREIGN_CAPACITY ? h[CTR_FOREIGN - CTR_SPILL] : FOREIGN_CAPACITY;
     if (h[ptd::CTR_POOL_ABORT - CTR_SPILL] != 0)
-        return fail(PTGPU_E_INTERNAL, "the pooled integrator (PTGPU_PT_POOL=1) gave a launch up after a wave waited %lld ticks: the pass's image is incomplete",
-                    (long long)ptd::POOL_WATCHDOG_TICKS);
+        return fail(PTGPU_E_INTERNAL, "the pooled integrator (PTGPU_PT_POOL=1) gave a launch up after a wave waited 2^%d ticks: the pass's image is incomplete",
+                    env_int("PTGPU_POOL_WATCHDOG_LOG2", ptd::POOL_WATCHDOG_LOG2) & 63);
     return PTGPU_OK;
 }
 
@@ -1296,9 +1317,11 @@ extern "C" int ptgpu_render_pass(ptgpu_scene* s, const ptgpu_params* prm, const 
     if (rc != PTGPU_OK) return rc;
     HIP_TRY(hipMemcpyAsync(accum, d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    unsigned long long ovf = 0;
-    HIP_TRY(hipMemcpy(&ovf, c->d_counters + CTR_DROPPED, sizeof ovf, hipMemcpyDeviceToHost));
-    if (ovf) return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples of this pass did not fit the spill lists and were dropped", ovf);
+    unsigned long long h[4];  // CTR_DROPPED .. CTR_POOL_ABORT
+    static_assert(ptd::CTR_POOL_ABORT == CTR_DROPPED + 3, "one copy covers both words");
+    HIP_TRY(hipMemcpy(h, c->d_counters + CTR_DROPPED, sizeof h, hipMemcpyDeviceToHost));
+    if (h[3]) return fail(PTGPU_E_INTERNAL, "the pooled integrator (PTGPU_PT_POOL=1) gave a launch up (watchdog): the pass's image is incomplete");
+    if (h[0]) return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples of this pass did not fit the spill lists and were dropped", h[0]);
     return PTGPU_OK;
 }
 
@@ -1384,6 +1407,49 @@ __global__ void k_light_to_sample(const ptgpu_light* __restrict__ lights, int nu
     R.key = rng_state[2 * i]; R.ctr = rng_state[2 * i + 1];
     out2[2 * i] = ptd::get_light_to_sample(ptd::ld3(pos + 3 * i), lights, num_lights, R);
     out2[2 * i + 1] = (int32_t)R.ctr;
+}
+
+// sobol::sample(index, dimension) (reference src/sobol.h:39-49) for n (index, dimension) pairs, through the device functions the kernels
+// draw their samples with: the byte-indexed pair table + bit loop of sobol32x2 for indices below 2^32 (every index the kernels form), the
+// reference's own 52-step loop beyond.
+__global__ void k_sobol_sample(const uint2* __restrict__ pairs, long long n, const unsigned long long* __restrict__ index,
+                               const uint32_t* __restrict__ dimension, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long idx = index[i];
+    const uint32_t dim = dimension[i];
+    if (idx >> 32) {
+        uint32_t result = 0u;
+        for (unsigned k = dim * 52u; idx; idx >>= 1, ++k)
+            if (idx & 1ull) result ^= ptd::g_sobol_matrices[k];
+        out[i] = (float)result * (1.f / 4294967296.f);
+    } else {
+        float a, b;
+        ptd::sobol32x2(pairs, (uint32_t)idx, dim & ~1u, a, b);
+        out[i] = (dim & 1u) ? b : a;
+    }
+}
+
+extern "C" int ptgpu_sobol_sample_batch(ptgpu_context* c, int64_t n, const uint64_t* index, const uint32_t* dimension, float* out) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    if (n < 0 || n > (1LL << 28)) return fail(PTGPU_E_INVALID, "n = %lld out of range", (long long)n);
+    if (n == 0) return PTGPU_OK;
+    if (!index || !dimension || !out) return fail(PTGPU_E_INVALID, "NULL array");
+    for (int64_t i = 0; i < n; ++i)
+        if (dimension[i] >= 1024u) return fail(PTGPU_E_INVALID, "dimension[%lld] = %u: the table has 1024 dimensions (sobol.h:40 asserts)", (long long)i, dimension[i]);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)n, b8 = (N * 8 + 255) & ~(size_t)255, b4 = (N * 4 + 255) & ~(size_t)255;
+    int rc = ensure_stage(c, b8 + 2 * b4);
+    if (rc != PTGPU_OK) return rc;
+    unsigned char* b = c->d_stage;
+    HIP_TRY(hipMemcpyAsync(b, index, N * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(b + b8, dimension, N * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_sobol_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_sobol_pairs, (long long)n,
+                       (const unsigned long long*)b, (const uint32_t*)(b + b8), (float*)(b + b8 + b4));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, b + b8 + b4, N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PTGPU_OK;
 }
 
 extern "C" int ptgpu_texture_parameters_batch(ptgpu_scene* s, const ptgpu_params* prm, int64_t n, const int32_t* tri, const float* u, const float* v,

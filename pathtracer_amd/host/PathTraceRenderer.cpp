@@ -268,12 +268,17 @@ void PathTraceRenderer::waitPass() {
 void PathTraceRenderer::stop() {
     m_context.m_bForceExit = true;
     if (m_running) {
-        // a device pass cannot be cancelled half-way; it is short (the reference waits for its worker threads the same way)
+        // reference :918-930: the workers see m_bForceExit before their next sample (:709,736) and stop() only waits for them to return;
+        // no pass is counted and no picture written.  Here the device's persistent waves see ptgpu_cancel's word at their next chunk of
+        // samples, batches that are not complete are left out of the accumulation image, and the stream drains in milliseconds.
         if (m_passInFlight) {
-            PT_GPU(ptgpu_sync(GpuDevice::instance().ctx()));
-            checkFinish();
+            ptgpu_context* ctx = GpuDevice::instance().ctx();
+            PT_GPU(ptgpu_cancel(ctx));
+            PT_GPU(ptgpu_sync(ctx));
+            m_passInFlight = false;
         }
         m_running = false;
+        if (m_printStats) std::printf("\nStopped!\n");
     }
     m_context.m_bForceExit = false;
 }

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "3d/CameraControls.hpp"
@@ -261,6 +262,46 @@ int pth_pt_render(void* h, const float eye[3], const float fwd[3], const float u
         if (out_accum) std::memcpy(out_accum, r.m_context.m_image->getPtr(), n);
         if (out_resolved) std::memcpy(out_resolved, dest.getPtr(), n);
         if (stats) { stats[0] = r.getTotalRays(); stats[1] = (uint64_t)r.m_context.m_pass; }
+    });
+}
+
+// startPathTracingProcess, then PathTraceRenderer::stop() after stop_after_ms while the first pass is still in flight (reference
+// :918-930).  out_ms[0] = how long stop() took, out_ms[1] = 1 if the pass was still running when stop() was called.  out_accum: the
+// accumulation image as stop() left it.
+int pth_pt_render_stop(void* h, const float eye[3], const float fwd[3], const float up[3], float fov, float nearD, float farD, int width, int height,
+                       const ptgpu_light* lights, int num_lights, const ptgpu_params* prm, int stop_after_ms, float* out_accum, double out_ms[2]) {
+    return guarded([&] {
+        TracerBox* b = static_cast<TracerBox*>(h);
+        CameraControls cam(Vec3f(eye[0], eye[1], eye[2]), Vec3f(fwd[0], fwd[1], fwd[2]), Vec3f(up[0], up[1], up[2]), fov, nearD, farD);
+        std::vector<AreaLight> ls;
+        for (int i = 0; i < num_lights; ++i) {
+            const ptgpu_light& p = lights[i];
+            AreaLight l(Vec3f(p.E[0], p.E[1], p.E[2]), Vec2f(p.size[0], p.size[1]), p.intensity);
+            Mat4f X;
+            std::memcpy(X.m, p.xform, 64);
+            l.setOrientation(X.getXYZ());
+            l.setPosition(X.getCol(3).getXYZ());
+            l.updatePower();
+            ls.push_back(l);
+        }
+        PathTraceRenderer r;
+        r.setAAmode(prm->sobol_block != 0); r.setAArays(prm->num_aa_rays); r.setAperture(prm->aperture); r.setAttenuation(prm->attenuation);
+        r.setBilinearFiltering(prm->bilinear != 0); r.setDOF(prm->depth_of_field != 0); r.setFilterWidth(prm->filter_width);
+        r.setFocalDistance(prm->focal_distance); r.setIntensity(prm->intensity); r.setLightRays(prm->num_light_rays);
+        r.setNormalMapped(prm->normal_mapped != 0); r.setTermination(prm->termination_prob); r.setWhitted(prm->whitted != 0);
+        r.setPrintStats(false);
+        b->rt.useAlpha = prm->use_alpha != 0;
+        Image dest(Vec2i(width, height), ImageFormat::RGBA_Vec4f);
+        r.startPathTracingProcess(b->mesh.get(), &ls, &b->rt, &dest, prm->bounces, cam);
+        std::this_thread::sleep_for(std::chrono::milliseconds(stop_after_ms));
+        r.checkFinish();  // as the reference's UI loop does; starts no new pass unless this one is over
+        out_ms[1] = (r.isRunning() && r.m_context.m_pass == 0) ? 1.0 : 0.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        r.stop();
+        out_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (r.isRunning()) throw GpuError("stop() left the renderer running");
+        r.updatePicture(&dest);
+        if (out_accum) std::memcpy(out_accum, r.m_context.m_image->getPtr(), (size_t)width * height * 16);
     });
 }
 

@@ -57,6 +57,8 @@ def lib():
         L.pth_rt_raycast.argtypes = [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P]
         L.pth_pt_render.argtypes = [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int, C.POINTER(Params), C.c_int,
                                     C.c_int, C.c_int, _P, _P, _P]
+        L.pth_pt_render_stop.argtypes = [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int, C.POINTER(Params), C.c_int,
+                                         _P, _P]
         L.pth_pt_statics.argtypes = [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P, C.c_int, C.POINTER(Params), C.c_int,
                                      _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]
         L.pth_pt_texture_parameters.argtypes = [_P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]
@@ -256,3 +258,16 @@ class HostRayTracer:
         _check(lib().pth_pt_render(self.h, e.ctypes.data, f.ctypes.data, u.ctypes.data, fov_deg, near, far, w, h, C.cast(larr, _P), len(lights),
                                    C.byref(params), passes, block_begin, block_stride, accum.ctypes.data, resolved.ctypes.data, st.ctypes.data))
         return accum, resolved, int(st[0]), int(st[1])
+
+    def path_trace_then_stop(self, params, lights, stop_after_ms, eye=(0.0, 0.0, 0.48), forward=(0.0, -0.1, -1.0), up=(0.0, 1.0, 0.0), fov_deg=70.0,
+                             near=0.001, far=3.0):
+        """startPathTracingProcess, then FW::PathTraceRenderer::stop() after stop_after_ms (reference src/PathTraceRenderer.cpp:918-930).
+        Returns (accumulation image as stop() left it, milliseconds stop() took, whether the first pass was still running)."""
+        w, h = params.width, params.height
+        accum = np.empty((h, w, 4), np.float32)
+        ms = np.zeros(2, np.float64)
+        e, f, u = _f32(eye), _f32(forward), _f32(up)
+        larr = (Light * len(lights))(*lights)
+        _check(lib().pth_pt_render_stop(self.h, e.ctypes.data, f.ctypes.data, u.ctypes.data, fov_deg, near, far, w, h, C.cast(larr, _P), len(lights),
+                                        C.byref(params), int(stop_after_ms), accum.ctypes.data, ms.ctypes.data))
+        return accum, float(ms[0]), bool(ms[1])

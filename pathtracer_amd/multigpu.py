@@ -93,7 +93,10 @@ class TileGather:
 
     def __init__(self, width, height, rank, world, device, ctx=None):
         """ctx given (a capi.Context on `device`): pack / unpack run as the library's kernels and only the all_gather goes through
-        torch.distributed, staged on the host when the backend is gloo.  ctx None: CPU tensors, everything in torch."""
+        torch.distributed, staged on the host when the backend is gloo.  ctx None: CPU tensors, everything in torch.
+        Stream order with ctx given: pack / unpack run on the CONTEXT's stream, the transport on torch's current stream, and the two may
+        differ (a default Context owns a non-blocking stream), so gather() joins them on the host: the context's stream is drained after
+        the pack and torch's stream before the unpack.  The caller's render pass and the gather are ordered by the context's stream."""
         self.width, self.height, self.rank, self.world, self.ctx = width, height, rank, world, ctx
         self.device = torch.device(device)
         self.floats = slice_floats(width, height, world)
@@ -113,9 +116,9 @@ class TileGather:
             return accum
         if self.ctx is not None:
             self.ctx.tiles_pack_dev(self.width, self.height, self.world, self.rank, accum.data_ptr(), self.send.data_ptr())
+            self.ctx.sync()  # `send` is complete before the transport (on torch's stream) reads it
             if self.world > 1:
                 if dist.get_backend() == "gloo":
-                    torch.cuda.synchronize(self.device)
                     host = torch.empty(self.recv.shape, dtype=torch.float32)
                     dist.all_gather_into_tensor(host, self.send.cpu())
                     self.recv.copy_(host)
@@ -123,6 +126,7 @@ class TileGather:
                     dist.all_gather_into_tensor(self.recv, self.send)
             else:
                 self.recv.copy_(self.send)
+            torch.cuda.current_stream(self.device).synchronize()  # `recv` is complete before the unpack (on the context's stream) reads it
             self.ctx.tiles_unpack_dev(self.width, self.height, self.world, self.rank, self.recv.data_ptr(), accum.data_ptr())
             return accum
         img = accum.view(-1, 4)

@@ -244,3 +244,45 @@ def test_trace_frame_equals_the_four_launch_sequence(gpu_ctx, head_gpu, size, mo
         assert gpu_ctx.counters()["rays"] == n + hits  # one raycast() per pixel plus one per hit
     for p in (d_o, d_d, d_so, d_sd, d_id, d_t, d_u, d_v, d_valid, d_sid, f_id, f_t, f_u, f_v, f_sid):
         gpu_ctx.free(p)
+
+
+def test_trace_frame_equals_the_oracle_at_1080p(gpu_ctx, head_gpu, head, oracle):
+    """The kernel the headline number times, compared DIRECTLY with the oracle on the configs[1] frame: primary hit records
+    (RayTracer::raycast closest-hit, reference src/RayTracer.cpp:174-290) and the shadow ray's occluder (any-hit, :235-238) for the
+    shadow rays oracle.gen_shadow builds (src/PathTraceRenderer.cpp:338-344) -- 2,073,600 pixels, every word."""
+    W, H = 1920, 1080
+    n = W * H
+    cam, light = scene.make_camera(width=W, height=H), scene.make_light()
+    f_id, f_t, f_u, f_v, f_sid = (gpu_ctx.malloc(n * 4) for _ in range(5))
+    for p in (f_id, f_t, f_u, f_v, f_sid):
+        capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, p, 0xEE, n * 4))
+    head_gpu.trace_frame_dev(cam, light, W, H, f_id, f_t, f_u, f_v, f_sid)
+    g = dict(id=gpu_ctx.d2h(f_id, n, np.int32), t=gpu_ctx.d2h(f_t, n, np.float32), u=gpu_ctx.d2h(f_u, n, np.float32),
+             v=gpu_ctx.d2h(f_v, n, np.float32))
+    gs = gpu_ctx.d2h(f_sid, n, np.int32)
+    for p in (f_id, f_t, f_u, f_v, f_sid):
+        gpu_ctx.free(p)
+    o, d = oracle.gen_primary(cam, W, H)
+    c = oracle.raycast(head["sd"], o, d, False, nthreads=8)
+    _assert_same(g, c, "trace_frame primary")
+    so, sdir, valid = oracle.gen_shadow(head["sd"], light, o, d, c)
+    cs = oracle.raycast(head["sd"], so, sdir, True, nthreads=8)
+    m = valid == 1
+    assert m.sum() > n // 10 and np.array_equal(gs[m], cs["id"][m]) and (gs[~m] == -1).all()
+    assert 0.05 < (cs["id"][m] >= 0).mean() < 0.95  # both outcomes of the shadow ray occur
+
+
+def test_trace_frame_rejects_a_tile_width_it_was_not_built_for(gpu_ctx, head_gpu, monkeypatch):
+    cam, light = scene.make_camera(width=64, height=64), scene.make_light()
+    bufs = [gpu_ctx.malloc(64 * 64 * 4) for _ in range(5)]
+    try:
+        for bad in ("0", "5", "128"):
+            monkeypatch.setenv("PTGPU_FRAME_TILE_W", bad)
+            with pytest.raises(capi.PtgpuError, match="PTGPU_FRAME_TILE_W"):
+                head_gpu.trace_frame_dev(cam, light, 64, 64, *bufs)
+        monkeypatch.setenv("PTGPU_FRAME_TILE_W", "16")
+        head_gpu.trace_frame_dev(cam, light, 64, 64, *bufs)
+        gpu_ctx.sync()
+    finally:
+        for b in bufs:
+            gpu_ctx.free(b)

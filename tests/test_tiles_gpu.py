@@ -128,6 +128,36 @@ def test_rccl_single_rank_communicator(gpu_ctx, head):
         s.close()
 
 
+def test_tile_gather_class_with_a_context_on_its_own_stream(head):
+    """multigpu.TileGather(ctx=...): pack / unpack run on the context's stream (a default Context owns a non-blocking stream), the
+    transport on torch's; the class joins the two.  One rank (the world == 1 path: pack -> device copy on torch's stream -> unpack): the
+    image survives the round trip unchanged."""
+    import torch
+
+    from pathtracer_amd import multigpu
+    w, h = 200, 120
+    cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]
+    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=False, filter_width=1.5, pass_seed=4)
+    ctx = capi.Context(0)  # its own stream: not torch's
+    s = capi.Scene(ctx, head["sd"])
+    try:
+        dev = torch.device("cuda", 0)
+        accum = torch.zeros(h * w * 4, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        s.render_pass_dev(prm, cam, lights, accum.data_ptr())
+        ctx.sync()
+        before = accum.cpu().numpy().reshape(h, w, 4).copy()
+        tg = multigpu.TileGather(w, h, 0, 1, dev, ctx=ctx)
+        for _ in range(3):  # repeated: a missing join between the two streams shows as a stale or half-written buffer
+            tg.gather(accum)
+        ctx.sync()
+        after = accum.cpu().numpy().reshape(h, w, 4)
+        assert before[..., 3].min() == 1.0 and np.array_equal(before.view(np.uint32), after.view(np.uint32))
+    finally:
+        s.close()
+        ctx.close()
+
+
 _RANK_SCRIPT = r"""
 import os, sys, time
 import numpy as np

@@ -78,3 +78,29 @@ def test_pooled_integrator_empty_scene(gpu_ctx):
     finally:
         s.close()
     assert ra == rb == w * h * 64 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_pooled_integrator_watchdog_reports_and_recovers(gpu_ctx, head, monkeypatch):
+    """The watchdog's exit path: with a bound of 2^4 ticks every wave that has to wait at all gives the launch up -- ptgpu_render_pass
+    and ptgpu_spill_status return PTGPU_E_INTERNAL (the image is incomplete), the device is not hung, and the next passes on the same
+    context (pooled with the normal bound, and the default integrator) are bit-identical to each other again."""
+    w, h = 200, 120
+    cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]
+    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=8, sobol_block=True, pass_seed=3)
+    s = capi.Scene(gpu_ctx, head["sd"])
+    try:
+        monkeypatch.setenv("PTGPU_PT_POOL", "1")
+        monkeypatch.setenv("PTGPU_POOL_WATCHDOG_LOG2", "4")
+        with pytest.raises(capi.PtgpuError, match="pooled integrator"):
+            s.render_pass(prm, cam, lights)
+        with pytest.raises(capi.PtgpuError, match="pooled integrator"):
+            gpu_ctx.spill_status()
+        monkeypatch.delenv("PTGPU_POOL_WATCHDOG_LOG2")
+        b = s.render_pass(prm, cam, lights)
+        assert gpu_ctx.spill_status()["dropped"] == 0  # the abort word is per pass: cleared
+        monkeypatch.setenv("PTGPU_PT_POOL", "0")
+        a = s.render_pass(prm, cam, lights)
+        gpu_ctx.spill_status()
+    finally:
+        s.close()
+    assert a[..., 3].min() > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -121,3 +121,43 @@ def test_noalloc_alpha_variant_and_limits(gpu_ctx, soup):
         s.raycast_dev_noalloc(None, None, 0, False, None, None, None, None)  # empty batch: nothing to do
     finally:
         s.close()
+
+
+def test_noalloc_allocates_no_device_memory(gpu_ctx, oracle, soup):
+    """The property the entry point exists for: free device memory (hipMemGetInfo, through torch.cuda.mem_get_info) is the same before
+    and after its calls -- on the 49-level tree, where ptgpu_raycast_batch_dev would size a deferred-ray list and overflow stacks, and on
+    the alpha variant -- while the allocating entry point on a FRESH context, same rays, is seen to take memory (so the probe can see it)."""
+    import torch
+    pos = _chain_scene()
+    nodes, lst, _ = oracle.bvh_build(pos, False)
+    sd = dict(pos=pos, nrm=scene.flat_normals(pos), uv=np.zeros((pos.shape[0], 3, 2), np.float32), mat_id=np.zeros(pos.shape[0], np.int32),
+              woop=oracle.woop_from_positions(pos), materials=[scene.make_material()], textures=[], nodes=nodes, list=lst)
+    n = 3_000_000  # a 12 MB deferred-ray list for the allocating path: above the allocator's granularity
+    rng = np.random.RandomState(8)
+    o = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n)], 1).astype(np.float32)
+    ts = (2.0 ** rng.uniform(0, 59, n)).astype(np.float32)
+    d = ((np.stack([ts, rng.uniform(-0.3, 0.3, n) * ts, rng.uniform(-0.3, 0.3, n) * ts], 1).astype(np.float32) - o) * np.float32(1.5)).astype(np.float32)
+    ctx = capi.Context(0)  # fresh: its grow-only buffers are empty
+    s = capi.Scene(ctx, sd)
+    d_o, d_d = ctx.to_device(o), ctx.to_device(d)
+    bufs = [ctx.malloc(n * 4) for _ in range(4)]
+    try:
+        ctx.sync()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        for occ in (False, True):
+            s.raycast_dev_noalloc(d_o, d_d, n, occ, *bufs)
+            s.raycast_dev_noalloc(d_o, d_d, n // 7, occ, *bufs)
+        ctx.sync()
+        free1 = torch.cuda.mem_get_info(0)[0]
+        assert free1 == free0, "ptgpu_raycast_batch_dev_noalloc changed free device memory by %d bytes" % (free0 - free1)
+        got = ctx.d2h(bufs[0], n // 7, np.int32)
+        s.raycast_dev(d_o, d_d, n, True, *bufs)  # the allocating entry point: deferred-ray list + overflow stacks appear
+        ctx.sync()
+        free2 = torch.cuda.mem_get_info(0)[0]
+        assert free2 < free1, "the probe cannot see the allocating entry point allocate"
+        assert np.array_equal(ctx.d2h(bufs[0], n // 7, np.int32), got)
+    finally:
+        for b in bufs + [d_o, d_d]:
+            ctx.free(b)
+        s.close()
+        ctx.close()
