@@ -141,6 +141,8 @@ int ptgpu_query(ptgpu_context* ctx, int* out_done);
 /* device memory for callers that have no allocator of their own (the C++ host classes) */
 int ptgpu_malloc(ptgpu_context* ctx, uint64_t bytes, void** out_dev);
 int ptgpu_free(ptgpu_context* ctx, void* dev);
+/* free / total device memory of the context's GPU (hipMemGetInfo): lets a caller of ptgpu_raycast_batch_dev_noalloc verify that it allocates nothing */
+int ptgpu_mem_info(ptgpu_context* ctx, uint64_t* out_free_bytes, uint64_t* out_total_bytes);
 int ptgpu_memcpy_h2d(ptgpu_context* ctx, void* dev, const void* host, uint64_t bytes);
 int ptgpu_memcpy_d2h(ptgpu_context* ctx, void* host, const void* dev, uint64_t bytes);
 int ptgpu_memset(ptgpu_context* ctx, void* dev, int value, uint64_t bytes);
@@ -213,11 +215,12 @@ int ptgpu_render_pass(ptgpu_scene* scene, const ptgpu_params* params, const ptgp
                       int32_t num_lights, int32_t block_begin, int32_t block_end, int32_t block_stride, float* accum);
 /* PathTraceRenderer::stop() while a pass is running: the reference's workers poll m_bForceExit before every sample and return
  * (src/PathTraceRenderer.cpp:709,736), and stop() waits only for that (:918-930).  ptgpu_cancel cancels every render pass enqueued on the
- * context so far: the integrator's persistent waves poll a cancel word when they draw a new chunk of samples and draw no more, the samples
+ * context so far: the integrator's persistent waves read a cancel word in device memory when they draw a new chunk of samples and draw no more, the samples
  * in flight run to their end, and a batch of blocks whose samples are not all there is NOT accumulated -- so d_accum is left holding whole
  * batches only (finite, a valid partial image) and the stream drains within milliseconds; ptgpu_sync / ptgpu_query then report
- * completion as usual.  Passes enqueued after the call are not affected.  Makes no HIP call: callable from any thread at any time,
- * in particular while another thread is blocked in ptgpu_sync or in the host-pointer ptgpu_render_pass. */
+ * completion as usual.  Passes enqueued after the call are not affected.  The call itself only enqueues a one-wave kernel on a
+ * high-priority stream of the context and does not wait; it may be made from any thread, in particular while another thread is
+ * blocked in ptgpu_sync or in the host-pointer ptgpu_render_pass. */
 int ptgpu_cancel(ptgpu_context* ctx);
 
 /* ---- the reference's static per-sample functions (src/PathTraceRenderer.hpp:97-102), evaluated by the same device code the render pass runs.

@@ -80,6 +80,7 @@ SIGNATURES = [
     ("ptgpu_query", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("ptgpu_malloc", C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     ("ptgpu_free", C.c_int, [_P, _P]),
+    ("ptgpu_mem_info", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("ptgpu_memcpy_h2d", C.c_int, [_P, _P, _P, C.c_uint64]),
     ("ptgpu_memcpy_d2h", C.c_int, [_P, _P, _P, C.c_uint64]),
     ("ptgpu_memset", C.c_int, [_P, _P, C.c_int, C.c_uint64]),
@@ -191,6 +192,12 @@ class Context:
         p = _P()
         _check(self.lib.ptgpu_malloc(self.handle, nbytes, C.byref(p)))
         return p.value
+
+    def mem_info(self):
+        """(free, total) bytes of device memory on the context's GPU."""
+        f, t = C.c_uint64(), C.c_uint64()
+        _check(self.lib.ptgpu_mem_info(self.handle, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def free(self, p):
         _check(self.lib.ptgpu_free(self.handle, p))

@@ -70,10 +70,10 @@ struct ptgpu_context {
     size_t stage_bytes = 0;
     unsigned char* scratch = nullptr;  // THIS device's address of the file-scope scratch array (ptgpu_raycast_batch_dev_noalloc)
     ptgpu_comm* comm = nullptr;        // tile-gather communicator (ptgpu_comm_init), owned
-    // ptgpu_cancel: one word of pinned, host-coherent memory = number of the last cancelled render pass; the kernels of pass number
-    // pass_epoch read it through d_cancel.  Written by the host with a plain atomic store: no HIP call, any thread.
-    uint32_t* h_cancel = nullptr;
+    // ptgpu_cancel: d_cancel (the last word of d_counters) = number of the last cancelled render pass, stored by a one-wave kernel on
+    // cancel_stream; the kernels of pass number pass_epoch compare it with their own number.
     uint32_t* d_cancel = nullptr;
+    hipStream_t cancel_stream = nullptr;
     std::atomic<uint32_t> pass_epoch{0};
 };
 

@@ -47,15 +47,20 @@ struct PassDesc {
     const uint32_t* ext_rng;
     uint32_t num_ext;
     // Cancellation (ptgpu_cancel; the reference's workers poll m_bForceExit before every sample, src/PathTraceRenderer.cpp:709,736): a word
-    // in host-coherent memory that holds the number of the last cancelled pass; this launch belongs to pass `epoch`.  NULL: never cancelled.
+    // in device memory that holds the number of the last cancelled pass, stored by ptgpu_cancel's one-wave kernel on a stream of its own
+    // while this launch runs; this launch belongs to pass `epoch`.  NULL: never cancelled.
     const uint32_t* cancel;
     uint32_t epoch;
 };
 
-// has the pass this launch belongs to been cancelled?  (wave-uniform; one uncached read of host memory: call it rarely)
+// Has the pass this launch belongs to been cancelled?  Wave-uniform; one agent-scope load (coherent with the agent-scope store of
+// k_cancel_set whichever XCD either runs on).
 __device__ __forceinline__ bool pass_cancelled(const PassDesc& pd) {
+#ifdef PT_NO_CANCEL  // A/B builds only (tools/build_variant.sh): what the poll costs
+    return false;
+#endif
     if (!pd.cancel) return false;
-    const uint32_t w = __hip_atomic_load(pd.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t w = __hip_atomic_load(pd.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (int32_t)(__builtin_amdgcn_readfirstlane(w) - pd.epoch) >= 0;
 }
 
@@ -300,9 +305,6 @@ __device__ __forceinline__ int block_sobol_base(int idx, uint32_t pass_seed) {
 #endif
 #ifndef PT_PHASE_BIAS_T
 #define PT_PHASE_BIAS_T 1  // a node phase when node lanes are at least as many as triangle lanes (with wave priorities: 1:1 19.2 ms, 2:1 19.45, 3:1 19.8; without them 2:1 was best)
-#endif
-#ifndef PT_CANCEL_EVERY
-#define PT_CANCEL_EVERY 4u  // power of two
 #endif
 #ifndef PT_STEPS_PER_ITERATION
 #define PT_STEPS_PER_ITERATION 3
@@ -599,9 +601,8 @@ __device__ __forceinline__ void integrate(const TravScene& TS, const ShadeScene&
                         // round r hands this wave chunk r*W + (w + 997 r) mod W: rotating the assignment every round keeps one wave
                         // from drawing the same image region (all cheap or all expensive) in every round
                         round = __builtin_amdgcn_readfirstlane(round + 1u);
-                        // a cancelled pass hands out no more samples (the ones in flight run to their end); polled every PT_CANCEL_EVERY-th
-                        // chunk of a wave: the word lives in host memory
-                        if (!EXT && (round & (PT_CANCEL_EVERY - 1u)) == 0u && pass_cancelled(pd)) { exhausted = true; break; }
+                        // a cancelled pass hands out no more samples (the ones in flight run to their end)
+                        if (!EXT && pass_cancelled(pd)) { exhausted = true; break; }
                         const unsigned long long cbase = ((unsigned long long)round * total_waves + (wave_id + (round % total_waves) * 997u) % total_waves) * 64ull;
                         if (cbase >= (unsigned long long)total) { exhausted = true; break; }
                         next = __builtin_amdgcn_readfirstlane((uint32_t)cbase);

@@ -558,10 +558,10 @@ __device__ __forceinline__ void pool_shade_wave(const TravScene& TS, const Shade
             // new samples for the idle slots
             const unsigned long long need = __ballot(slot >= 0 && ps.stage == ST_IDLE);
             if (need != 0ull) {
-                const bool cancelled = pass_cancelled(pd);  // ptgpu_cancel: the slots retire as if the range were exhausted
                 uint32_t cbase = 0;
                 if (lane == 0) cbase = atomicAdd(&ctl->cursor, (uint32_t)__popcll(need));
                 cbase = (uint32_t)__shfl((int)cbase, 0);
+                const bool cancelled = pass_cancelled(pd);  // ptgpu_cancel: the slots retire as if the range were exhausted
                 if (slot >= 0 && ps.stage == ST_IDLE) {
                     const uint32_t cc = cbase + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                     // round r of this workgroup draws chunk r * G + (g + 997 r) mod G of the launch's range (rotated so that a workgroup does

@@ -92,17 +92,20 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c);
 static int init_context(ptgpu_context* c, const hipDeviceProp_t& prop) {
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIP_TRY(hipMalloc(&c->d_counters, (CTR_WORDS + RAY_SPREAD) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_counters, 0, (CTR_WORDS + RAY_SPREAD) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->d_counters, (CTR_WORDS + RAY_SPREAD + 1) * sizeof(unsigned long long)));  // + the device copy of the cancel word
+    HIP_TRY(hipMemset(c->d_counters, 0, (CTR_WORDS + RAY_SPREAD + 1) * sizeof(unsigned long long)));
+    c->d_cancel = reinterpret_cast<uint32_t*>(c->d_counters + CTR_WORDS + RAY_SPREAD);
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int entries = ptd::SOBOL_PAIRS * 3 * 256;
     HIP_TRY(hipMalloc(&c->d_sobol_pairs, (size_t)entries * sizeof(uint2)));
     hipLaunchKernelGGL(k_build_sobol_pairs, dim3((entries + 255) / 256), dim3(256), 0, c->stream, c->d_sobol_pairs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipHostMalloc((void**)&c->h_cancel, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    *c->h_cancel = 0u;
-    HIP_TRY(hipHostGetDevicePointer((void**)&c->d_cancel, c->h_cancel, 0));
+    {   // ptgpu_cancel's stream: highest priority, so that its one-wave kernel is not queued behind the pass it cancels
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->cancel_stream, hipStreamNonBlocking, hi));
+    }
     return noalloc_scratch_address(&c->scratch);  // device `device` is current
 }
 
@@ -144,7 +147,7 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     if (c->d_stack_ovf) hipFree(c->d_stack_ovf);
     if (c->d_defer) hipFree(c->d_defer);
     if (c->d_sobol_pairs) hipFree(c->d_sobol_pairs);
-    if (c->h_cancel) hipHostFree(c->h_cancel);
+    if (c->cancel_stream) { hipStreamSynchronize(c->cancel_stream); hipStreamDestroy(c->cancel_stream); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return PTGPU_OK;
@@ -170,11 +173,17 @@ extern "C" int ptgpu_query(ptgpu_context* c, int* out_done) {
     return PTGPU_OK;
 }
 // Cancels every render pass enqueued on the context so far (ptgpu_render_pass[_dev] calls that have returned or are running in another
-// thread): their persistent waves stop drawing samples at their next poll, batches that were not complete are not accumulated, and the
-// stream drains within milliseconds.  Passes enqueued afterwards are not affected.  No HIP call: safe from any thread at any time.
+// thread): a one-wave kernel on the context's cancel stream stores the number of the last enqueued pass into the device word the
+// integrator's persistent waves read whenever they draw a new chunk of samples; they draw no more, batches that are not complete are
+// not accumulated, and the stream drains within milliseconds.  Passes enqueued afterwards are not affected.  Does not wait.
+__global__ void k_cancel_set(uint32_t* word, uint32_t epoch) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 extern "C" int ptgpu_cancel(ptgpu_context* c) {
-    if (!c || !c->h_cancel) return fail(PTGPU_E_INVALID, "ctx is NULL or not initialised");
-    __atomic_store_n(c->h_cancel, c->pass_epoch.load(std::memory_order_acquire), __ATOMIC_RELEASE);
+    if (!c || !c->d_cancel) return fail(PTGPU_E_INVALID, "ctx is NULL or not initialised");
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_cancel_set, dim3(1), dim3(64), 0, c->cancel_stream, c->d_cancel, c->pass_epoch.load(std::memory_order_acquire));
+    HIP_TRY(hipGetLastError());
     return PTGPU_OK;
 }
 
@@ -188,6 +197,15 @@ extern "C" int ptgpu_free(ptgpu_context* c, void* p) {
     if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     if (p) HIP_TRY(hipFree(p));
+    return PTGPU_OK;
+}
+extern "C" int ptgpu_mem_info(ptgpu_context* c, uint64_t* out_free, uint64_t* out_total) {
+    if (!c) return fail(PTGPU_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (out_free) *out_free = f;
+    if (out_total) *out_total = t;
     return PTGPU_OK;
 }
 extern "C" int ptgpu_memcpy_h2d(ptgpu_context* c, void* dev, const void* host, uint64_t bytes) {

@@ -128,34 +128,48 @@ def test_rccl_single_rank_communicator(gpu_ctx, head):
         s.close()
 
 
-def test_tile_gather_class_with_a_context_on_its_own_stream(head):
+_TILEGATHER_SCRIPT = r"""
+import sys
+import numpy as np
+import torch  # first: this process runs on torch's own HIP runtime (as bench.py does)
+sys.path.insert(0, %(root)r)
+from pathtracer_amd import capi, hostapi, multigpu, scene
+mesh = scene.load_ptmesh()
+nodes, lst, _ = hostapi.bvh_build(mesh["pos"], sah=True)
+sd = dict(pos=mesh["pos"], nrm=mesh["nrm"], uv=mesh["uv"], mat_id=mesh["mat_id"], woop=hostapi.woop_from_positions(mesh["pos"]),
+          materials=scene.mesh_materials(mesh), textures=[], nodes=nodes, list=lst)
+w, h = 200, 120
+cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]
+prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=False, filter_width=1.5, pass_seed=4)
+dev = torch.device("cuda", 0)
+ctx = capi.Context(0)  # its own non-blocking stream: not torch's
+s = capi.Scene(ctx, sd)
+accum = torch.zeros(h * w * 4, dtype=torch.float32, device=dev)
+torch.cuda.synchronize(dev)
+s.render_pass_dev(prm, cam, lights, accum.data_ptr())
+ctx.sync()
+before = accum.cpu().numpy().reshape(h, w, 4).copy()
+tg = multigpu.TileGather(w, h, 0, 1, dev, ctx=ctx)
+for _ in range(3):  # repeated: a missing join between the two streams shows as a stale or half-written buffer
+    tg.gather(accum)
+ctx.sync()
+after = accum.cpu().numpy().reshape(h, w, 4)
+assert before[..., 3].min() == 1.0 and before[..., :3].max() > 0.01
+assert np.array_equal(before.view(np.uint32), after.view(np.uint32)), "the image changed on its way through pack -> copy -> unpack"
+s.close()
+ctx.close()
+print("ok")
+"""
+
+
+def test_tile_gather_class_with_a_context_on_its_own_stream(tmp_path):
     """multigpu.TileGather(ctx=...): pack / unpack run on the context's stream (a default Context owns a non-blocking stream), the
     transport on torch's; the class joins the two.  One rank (the world == 1 path: pack -> device copy on torch's stream -> unpack): the
-    image survives the round trip unchanged."""
-    import torch
-
-    from pathtracer_amd import multigpu
-    w, h = 200, 120
-    cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]
-    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=2, sobol_block=False, filter_width=1.5, pass_seed=4)
-    ctx = capi.Context(0)  # its own stream: not torch's
-    s = capi.Scene(ctx, head["sd"])
-    try:
-        dev = torch.device("cuda", 0)
-        accum = torch.zeros(h * w * 4, dtype=torch.float32, device=dev)
-        torch.cuda.synchronize(dev)
-        s.render_pass_dev(prm, cam, lights, accum.data_ptr())
-        ctx.sync()
-        before = accum.cpu().numpy().reshape(h, w, 4).copy()
-        tg = multigpu.TileGather(w, h, 0, 1, dev, ctx=ctx)
-        for _ in range(3):  # repeated: a missing join between the two streams shows as a stale or half-written buffer
-            tg.gather(accum)
-        ctx.sync()
-        after = accum.cpu().numpy().reshape(h, w, 4)
-        assert before[..., 3].min() == 1.0 and np.array_equal(before.view(np.uint32), after.view(np.uint32))
-    finally:
-        s.close()
-        ctx.close()
+    image survives the round trip unchanged.  In a process of its own, where torch is loaded before the library."""
+    script = tmp_path / "tilegather.py"
+    script.write_text(_TILEGATHER_SCRIPT % dict(root=ROOT))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stdout[-500:] + p.stderr[-1500:]
 
 
 _RANK_SCRIPT = r"""

@@ -124,10 +124,9 @@ def test_noalloc_alpha_variant_and_limits(gpu_ctx, soup):
 
 
 def test_noalloc_allocates_no_device_memory(gpu_ctx, oracle, soup):
-    """The property the entry point exists for: free device memory (hipMemGetInfo, through torch.cuda.mem_get_info) is the same before
+    """The property the entry point exists for: free device memory (hipMemGetInfo, through ptgpu_mem_info) is the same before
     and after its calls -- on the 49-level tree, where ptgpu_raycast_batch_dev would size a deferred-ray list and overflow stacks, and on
     the alpha variant -- while the allocating entry point on a FRESH context, same rays, is seen to take memory (so the probe can see it)."""
-    import torch
     pos = _chain_scene()
     nodes, lst, _ = oracle.bvh_build(pos, False)
     sd = dict(pos=pos, nrm=scene.flat_normals(pos), uv=np.zeros((pos.shape[0], 3, 2), np.float32), mat_id=np.zeros(pos.shape[0], np.int32),
@@ -143,17 +142,17 @@ def test_noalloc_allocates_no_device_memory(gpu_ctx, oracle, soup):
     bufs = [ctx.malloc(n * 4) for _ in range(4)]
     try:
         ctx.sync()
-        free0 = torch.cuda.mem_get_info(0)[0]
+        free0 = ctx.mem_info()[0]
         for occ in (False, True):
             s.raycast_dev_noalloc(d_o, d_d, n, occ, *bufs)
             s.raycast_dev_noalloc(d_o, d_d, n // 7, occ, *bufs)
         ctx.sync()
-        free1 = torch.cuda.mem_get_info(0)[0]
+        free1 = ctx.mem_info()[0]
         assert free1 == free0, "ptgpu_raycast_batch_dev_noalloc changed free device memory by %d bytes" % (free0 - free1)
         got = ctx.d2h(bufs[0], n // 7, np.int32)
         s.raycast_dev(d_o, d_d, n, True, *bufs)  # the allocating entry point: deferred-ray list + overflow stacks appear
         ctx.sync()
-        free2 = torch.cuda.mem_get_info(0)[0]
+        free2 = ctx.mem_info()[0]
         assert free2 < free1, "the probe cannot see the allocating entry point allocate"
         assert np.array_equal(ctx.d2h(bufs[0], n // 7, np.int32), got)
     finally:
