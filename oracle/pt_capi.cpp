@@ -187,8 +187,10 @@ void pto_gen_shadow(const pto_scene* s, const pto_light* l, int64_t n, const flo
 }
 
 // One pass over blocks block_begin, block_begin + block_stride, ... < block_end.  Out-of-block samples are applied after every block is
-// done, in (block, sample) order: to accum when their pixel lies in one of this call's blocks, else appended to foreign_out
-// (8 floats each: r g b w, pixel as int bits, 3 pad -- the device's ForeignSpill) when given, else to accum as well.
+// done, in (block, sample) order.  foreign_out == NULL: all of them to accum.  foreign_out given (8 floats per entry: r g b w, then pixel,
+// source block, sample as int bits, 1 pad -- the device's ForeignSpill): with block_stride == 1 those whose pixel lies in one of this
+// call's blocks go to accum and the others to foreign_out; with block_stride > 1 (tiles sharded over ranks) ALL go to foreign_out, for
+// every rank to add every rank's after the exchange, per pixel in (source block, sample) order (pathtracer_amd/multigpu.TileGather).
 void pto_render_pass2(const pto_scene* s, const pto_params* p, const pto_camera* cam, const pto_light* lights, int nl,
                       float* accum, pto_counters* ctr, int nthreads, int libm, int block_begin, int block_end, int block_stride,
                       float* foreign_out, int foreign_cap, int* foreign_count) {
@@ -213,14 +215,16 @@ void pto_render_pass2(const pto_scene* s, const pto_params* p, const pto_camera*
         for (const Spill& sp : list) {
             const int idx = ((sp.pixel / p->width) >> 5) * blocks_x + ((sp.pixel % p->width) >> 5);
             const bool own = idx >= block_begin && idx < block_end && (idx - block_begin) % block_stride == 0;
-            if (own || !foreign_out) {
+            if (!foreign_out || (own && block_stride == 1)) {
                 float* px = accum + (size_t)sp.pixel * 4;
                 px[0] += sp.r; px[1] += sp.g; px[2] += sp.b; px[3] += sp.w;
             } else if (nf < foreign_cap) {
                 float* o = foreign_out + (size_t)nf * 8;
                 o[0] = sp.r; o[1] = sp.g; o[2] = sp.b; o[3] = sp.w;
                 std::memcpy(o + 4, &sp.pixel, 4);
-                o[5] = o[6] = o[7] = 0.0f;
+                std::memcpy(o + 5, &sp.src_block, 4);
+                std::memcpy(o + 6, &sp.sample, 4);
+                o[7] = 0.0f;
                 ++nf;
             }
         }

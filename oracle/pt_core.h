@@ -517,11 +517,13 @@ inline int block_sobol_base(int idx, uint32_t pass_seed) {
 // reference src/PathTraceRenderer.cpp:663-790, one block.  The reference threads ONE Random
 // through all samples of a block; this build gives every sample its own stream keyed by
 // (block, pass_seed, i, k) (documented deviation, SURVEY.md 7 "Sequential RNG").
-// A Sobol-block sample whose pixel lies outside its own block (sobol() rounds to exactly 1.0f): the reference's worker
-// thread adds it to the neighbouring block's pixel while another thread may be working on that block (a race).  This build defers
-// such samples to the end of the pass (device: k_apply_spill) and, with image tiles sharded over ranks, hands those that fall in
-// another rank's block to that rank (device: ptgpu_tiles_pack_dev); `spills` collects them in sample order.
-struct Spill { float r, g, b, w; int pixel; };
+// A Sobol-block sample whose pixel lies outside its own block (the position block.x + block.w * sobol() rounds up to the block's far
+// edge: sobol() == 1.0f exactly, SURVEY.md R8, or merely close to 1 when block.x is in the thousands -- some 30,000 samples of a 4K frame at
+// 1024 spp): the reference's worker thread adds it to the neighbouring block's pixel while another thread may be working on that
+// block (a race).  This build defers such samples to the end of the pass and adds them per pixel in (source block, sample) order
+// (device: ptgpu_apply_spills_sorted); with image tiles sharded over ranks they all travel with the tiles and every rank adds every
+// rank's after the exchange, in that same order (device: ptgpu_tiles_pack_dev / _unpack_dev).  `spills` collects them in sample order.
+struct Spill { float r, g, b, w; int pixel, src_block, sample; };
 
 template <class Mth>
 inline void path_trace_block(const pto_scene& s, const pto_params& prm, const pto_camera& cam, const pto_light* lights, int nl,
@@ -544,7 +546,7 @@ inline void path_trace_block(const pto_scene& s, const pto_params& prm, const pt
             int pixel_y = (int)std::floor(py); if (pixel_y > height - 1) pixel_y = height - 1;
             if (spills && (pixel_x < block.x || pixel_x >= block.x + block.w || pixel_y < block.y || pixel_y >= block.y + block.h)) {
                 spills->push_back(Spill{color.x * scaleToAaRays, color.y * scaleToAaRays, color.z * scaleToAaRays, 1.0f * scaleToAaRays,
-                                        pixel_y * width + pixel_x});
+                                        pixel_y * width + pixel_x, idx, i});
                 continue;
             }
             float* prev = accum + ((size_t)pixel_y * width + pixel_x) * 4;

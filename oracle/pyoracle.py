@@ -167,9 +167,10 @@ def render_pass(sd, params, cam, lights, accum=None, nthreads=1, libm=False, blo
     return accum, dict(rays=ctr.rays, node_visits=ctr.node_visits, tri_tests=ctr.tri_tests)
 
 
-def render_pass_tiles(sd, params, cam, lights, accum, block_begin, block_stride, nthreads=1, foreign_cap=1024):
+def render_pass_tiles(sd, params, cam, lights, accum, block_begin, block_stride, nthreads=1, foreign_cap=65536):
     """One pass over this rank's blocks (block_begin, block_begin + stride, ...).  Returns (accum, foreign [n,8] float32, counters):
-    foreign = the out-of-block samples that landed in another rank's block, in the device's ForeignSpill layout."""
+    foreign = with block_stride > 1 ALL out-of-block samples of the pass (they travel with the tiles), with block_stride == 1 those
+    outside this call's blocks; in the device's ForeignSpill layout (r g b w, pixel, source block, sample, pad)."""
     desc, keep = make_scene_desc(sd)
     larr = (Light * len(lights))(*lights)
     ctr = Counters()

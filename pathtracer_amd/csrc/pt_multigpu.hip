@@ -5,10 +5,11 @@
 // threads write disjoint blocks of one shared image (src/PathTraceRenderer.cpp:727-732, :785-787).
 //
 // Wire format of one rank's slice (floats): blocks_per_rank x 1024 pixels x 4 (block j of the rank in slot j, row-major inside the
-// block, pixels outside an edge-clipped block zero), then the foreign-spill section: one float4 header (count as int bits) and
-// FOREIGN_CAPACITY entries of two float4 (pt_context.h ForeignSpill) -- Sobol-block samples that landed one pixel outside their block
-// (sobol() == 1.0f exactly) in a block of another rank.  After the exchange every rank adds every rank's foreign entries to the full
-// image, in rank order, so all ranks end with the same image and no sample is lost.
+// block, pixels outside an edge-clipped block zero), then the out-of-block section: one float4 header (count as int bits) and
+// FOREIGN_CAPACITY entries of two float4 (pt_context.h ForeignSpill) -- the Sobol-block samples of the rank's pass that landed one
+// pixel outside their block (ALL of them, whoever owns the pixel).  After the exchange every rank adds every rank's entries to the full
+// image, per pixel in (source block, sample) order (ptgpu_apply_spills_sorted) -- the order in which ONE process adds them -- so all
+// ranks end with the image one GPU renders, bit for bit, and no sample is lost.
 //
 // RCCL is loaded at run time (dlopen of librccl.so.1, found through this library's RUNPATH or already in the process with torch), so
 // single-GPU users of libptgpu.so do not load it.
@@ -86,8 +87,10 @@ __device__ __forceinline__ bool slot_pixel(const TileGrid& g, int rank, int j, i
     return true;
 }
 
+constexpr int PACK_SECTION_GROUPS = 32;  // workgroups that move the out-of-block section
+
 __global__ __launch_bounds__(256) void k_tiles_pack(TileGrid g, int rank, const float4* __restrict__ accum, float4* __restrict__ slice,
-                                                    const ForeignSpill* __restrict__ foreign, unsigned long long* counters) {
+                                                    const ForeignSpill* __restrict__ foreign, const unsigned long long* __restrict__ counters) {
     const int j = blockIdx.x;
     if (j < g.blocks_per_rank) {
         for (int p = threadIdx.x; p < TILE_PIXELS; p += 256) {
@@ -96,16 +99,18 @@ __global__ __launch_bounds__(256) void k_tiles_pack(TileGrid g, int rank, const 
         }
         return;
     }
-    // the last workgroup moves the foreign-spill section and empties the pending list
+    // the last workgroups move the out-of-block section (the pending list is emptied by k_tiles_pack_done, after this kernel)
     float4* sec = slice + (size_t)g.blocks_per_rank * TILE_PIXELS;
     unsigned long long n = counters[CTR_FOREIGN];
     if (n > (unsigned long long)FOREIGN_CAPACITY) n = FOREIGN_CAPACITY;
     const float4* src = reinterpret_cast<const float4*>(foreign);
-    for (int e = threadIdx.x; e < FOREIGN_CAPACITY * 2; e += 256)
+    const int part = j - g.blocks_per_rank;
+    for (int e = part * 256 + threadIdx.x; e < FOREIGN_CAPACITY * 2; e += PACK_SECTION_GROUPS * 256)
         sec[1 + e] = (unsigned long long)(e >> 1) < n ? src[e] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (threadIdx.x == 0) sec[0] = make_float4(__int_as_float((int)n), 0.0f, 0.0f, 0.0f);
-    __syncthreads();
-    if (threadIdx.x == 0) counters[CTR_FOREIGN] = 0ull;
+    if (part == 0 && threadIdx.x == 0) sec[0] = make_float4(__int_as_float((int)n), 0.0f, 0.0f, 0.0f);
+}
+__global__ void k_tiles_pack_done(unsigned long long* counters) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) counters[CTR_FOREIGN] = 0ull;
 }
 
 // every other rank's tiles into the full image (this rank's own pixels are already there)
@@ -117,25 +122,6 @@ __global__ __launch_bounds__(256) void k_tiles_unpack(TileGrid g, int rank, long
     for (int p = threadIdx.x; p < TILE_PIXELS; p += 256) {
         size_t at;
         if (slot_pixel(g, r, j, p, at)) accum[at] = slice[(size_t)j * TILE_PIXELS + p];
-    }
-}
-
-// Every rank's foreign entries, in rank order then list order, by ONE thread: the same additions in the same order on every rank
-// (a handful of entries per pass; several in one pixel would otherwise depend on atomic ordering).
-__global__ void k_tiles_apply_foreign(TileGrid g, long long slice_f4, const float4* __restrict__ gathered, float* __restrict__ accum) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (int r = 0; r < g.world; ++r) {
-        const float4* sec = gathered + (size_t)r * slice_f4 + (size_t)g.blocks_per_rank * TILE_PIXELS;
-        int n = __float_as_int(sec[0].x);
-        if (n < 0) n = 0;
-        if (n > FOREIGN_CAPACITY) n = FOREIGN_CAPACITY;
-        for (int e = 0; e < n; ++e) {
-            const float4 v = sec[1 + 2 * e], m = sec[2 + 2 * e];
-            const int gp = __float_as_int(m.x);
-            if (gp < 0 || gp >= g.width * g.height) continue;
-            float* px = accum + (size_t)gp * 4;
-            px[0] += v.x; px[1] += v.y; px[2] += v.z; px[3] += v.w;
-        }
     }
 }
 
@@ -215,8 +201,9 @@ extern "C" int ptgpu_tiles_pack_dev(ptgpu_context* c, int32_t width, int32_t hei
     HIP_TRY(hipSetDevice(c->device));
     rc = ptgpu_ensure_spill_lists(c);  // a caller may gather before its first Sobol-block pass
     if (rc != PTGPU_OK) return rc;
-    hipLaunchKernelGGL(k_tiles_pack, dim3((unsigned)g.blocks_per_rank + 1), dim3(256), 0, c->stream, g, (int)rank,
+    hipLaunchKernelGGL(k_tiles_pack, dim3((unsigned)g.blocks_per_rank + PACK_SECTION_GROUPS), dim3(256), 0, c->stream, g, (int)rank,
                        reinterpret_cast<const float4*>(d_accum), reinterpret_cast<float4*>(d_slice), c->d_foreign, c->d_counters);
+    hipLaunchKernelGGL(k_tiles_pack_done, dim3(1), dim3(64), 0, c->stream, c->d_counters);
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;
 }
@@ -233,9 +220,10 @@ extern "C" int ptgpu_tiles_unpack_dev(ptgpu_context* c, int32_t width, int32_t h
     if (world > 1)
         hipLaunchKernelGGL(k_tiles_unpack, dim3((unsigned)g.blocks_per_rank, (unsigned)world), dim3(256), 0, c->stream, g, (int)rank, sf4,
                            reinterpret_cast<const float4*>(d_slices), reinterpret_cast<float4*>(d_accum));
-    hipLaunchKernelGGL(k_tiles_apply_foreign, dim3(1), dim3(64), 0, c->stream, g, sf4, reinterpret_cast<const float4*>(d_slices), d_accum);
     HIP_TRY(hipGetLastError());
-    return PTGPU_OK;
+    // every rank's out-of-block samples, per pixel in (source block, sample) order
+    const SpillLists lists{reinterpret_cast<const float4*>(d_slices) + (size_t)g.blocks_per_rank * TILE_PIXELS + 1, sf4, FOREIGN_CAPACITY, world, nullptr};
+    return ptgpu_apply_spills_sorted(c, lists, d_accum, width, height, nullptr);
 }
 
 extern "C" int ptgpu_gather_tiles_dev(ptgpu_context* c, int32_t width, int32_t height, float* d_accum) {

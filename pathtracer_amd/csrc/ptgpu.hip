@@ -143,6 +143,7 @@ extern "C" int ptgpu_shutdown(ptgpu_context* c) {
     if (c->d_lights) hipFree(c->d_lights);
     ptgpu_comm_release(c);
     if (c->d_spill) hipFree(c->d_spill);
+    if (c->d_sort_ws) hipFree(c->d_sort_ws);
     if (c->d_foreign) hipFree(c->d_foreign);
     if (c->d_stack_ovf) hipFree(c->d_stack_ovf);
     if (c->d_defer) hipFree(c->d_defer);
@@ -952,7 +953,7 @@ extern "C" int ptgpu_gen_shadow_dev(ptgpu_scene* s, const ptgpu_light* light, in
 //   k_integrate        per-sample radiance (tracePath) -> rad[padded sample id]
 //   k_accum_sobol      m_sobolBlock == true:  pixel += (color, 1) / NumAaRays in sample order i (:727-732)
 //   k_accum_gauss      m_sobolBlock == false: Gaussian-weighted per-pixel mean over k, saturate, pixel += (:743-787)
-//   k_apply_spill      Sobol-block samples whose pixel lies outside their own block (sobol() rounds to 1.0f)
+//   k_spill_*          Sobol-block samples whose pixel lies outside their own block (the position rounds up to the block's far edge)
 //   k_resolve          updatePicture (:855-871)
 // ------------------------------------------------------------------------------------------------
 #ifndef PT_BLOCK_THREADS
@@ -1001,7 +1002,7 @@ __device__ __forceinline__ void block_rect(const ptgpu_params& prm, const ptd::P
 }
 
 __global__ __launch_bounds__(256) void k_accum_sobol(ptgpu_params prm, ptd::PassDesc pd, const float4* __restrict__ rad, float* __restrict__ accum,
-                                                     float4* __restrict__ spill, unsigned long long* counters) {
+                                                     ForeignSpill* __restrict__ spill, unsigned long long spill_capacity, unsigned long long* counters) {
     __shared__ float4 acc[1024];
     __shared__ int owner[1024];
     if (ptd::pass_cancelled(pd)) return;  // the batch's radiance may be incomplete: none of it is added (workgroup-uniform)
@@ -1031,8 +1032,10 @@ __global__ __launch_bounds__(256) void k_accum_sobol(ptgpu_params prm, ptd::Pass
                 lp = (gy - by) * 32 + (gx - bx);
                 pending = true;
             } else {
+                // one pixel outside this block (the position rounded up to the block's far edge): kept for the end of the pass
                 const unsigned long long slot = atomicAdd(&counters[CTR_SPILL], 1ull);
-                if (slot < (unsigned long long)SPILL_CAPACITY) spill[slot] = make_float4(r.x * scale, r.y * scale, r.z * scale, r.w);
+                if (slot < spill_capacity)
+                    spill[slot] = ForeignSpill{r.x * scale, r.y * scale, r.z * scale, 1.0f * scale, gp, pd.block_begin + (pd.j0 + jj) * pd.block_stride, i, 0};
                 else atomicAdd(&counters[CTR_DROPPED], 1ull);
             }
         }
@@ -1057,37 +1060,118 @@ __global__ __launch_bounds__(256) void k_accum_sobol(ptgpu_params prm, ptd::Pass
     }
 }
 
-// Which 32x32 blocks a render call accumulates (block_begin, block_begin + stride, ... < block_end): the pixels of every other block
-// belong to another call -- with tile sharding, to another GPU.
-struct TileOwner {
-    int32_t block_begin, block_end, block_stride, blocks_x;
-};
 __device__ __forceinline__ bool owns_pixel(const TileOwner& o, int gp, int width) {
     const int idx = ((gp / width) >> 5) * o.blocks_x + ((gp % width) >> 5);
     return idx >= o.block_begin && idx < o.block_end && (idx - o.block_begin) % o.block_stride == 0;
 }
 
-// Once per pass, after every block sum: out-of-block samples that landed in one of this call's own blocks are added to their pixel; those
-// that landed in a block this call does not render are kept in the context's foreign list for ptgpu_tiles_pack_dev /
-// ptgpu_gather_tiles_dev to deliver to the pixel's owner (adding them here would be overwritten by the owner's tile at the gather).
-__global__ void k_apply_spill(ptgpu_params prm, TileOwner own, const float4* __restrict__ spill, float* __restrict__ accum,
-                              ForeignSpill* __restrict__ foreign, unsigned long long* counters) {
-    unsigned long long n = counters[CTR_SPILL];
-    if (n > (unsigned long long)SPILL_CAPACITY) n = SPILL_CAPACITY;
-    const float scale = 1.0f / (float)prm.num_aa_rays;
-    for (unsigned long long e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * blockDim.x) {
-        const float4 s = spill[e];
-        const int gp = __float_as_int(s.w);
-        if (gp < 0 || gp >= prm.width * prm.height) continue;
-        if (owns_pixel(own, gp, prm.width)) {
-            float* px = accum + (size_t)gp * 4;
-            atomicAdd(px, s.x); atomicAdd(px + 1, s.y); atomicAdd(px + 2, s.z); atomicAdd(px + 3, 1.0f * scale);
-        } else {
+// ------------------------------------------------------------------------------------------------
+// Out-of-block samples (pt_context.h): added after the block sums, per pixel in (source block, sample) order, whatever order the lists
+// were filled in -- so one GPU, N GPUs and the sequential CPU loop produce the same bits even when several of them meet in one pixel.
+//   sort 1 (stable radix): key = invalid | source block | sample          sort 2 (stable radix): key = pixel
+//   then one thread per run of equal pixels walks its run and adds (or, for a pixel the call does not own, appends to the foreign list)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ const ForeignSpill* spill_entry(const SpillLists& L, uint32_t idx) {
+    return reinterpret_cast<const ForeignSpill*>(L.first + (size_t)(idx / (uint32_t)L.per_list) * L.list_stride_f4) + (idx % (uint32_t)L.per_list);
+}
+__device__ __forceinline__ uint32_t spill_list_count(const SpillLists& L, uint32_t list) {
+    long long n = L.local_count ? (long long)*L.local_count : (long long)__float_as_int((L.first + (size_t)list * L.list_stride_f4 - 1)->x);
+    return (uint32_t)(n < 0 ? 0 : (n > L.per_list ? L.per_list : n));
+}
+constexpr unsigned long long SPILL_KEY_INVALID = 1ull << 53;  // above the source block (21 bits at 32..52) and the sample (30 bits)
+__global__ __launch_bounds__(256) void k_spill_keys(SpillLists L, uint32_t m, int num_pixels, unsigned long long* __restrict__ key, uint32_t* __restrict__ idx) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= m) return;
+    unsigned long long k = SPILL_KEY_INVALID;
+    if (e % (uint32_t)L.per_list < spill_list_count(L, e / (uint32_t)L.per_list)) {
+        const ForeignSpill* s = spill_entry(L, e);
+        if (s->pixel >= 0 && s->pixel < num_pixels)
+            k = ((unsigned long long)((uint32_t)s->src_block & 0x1fffffu) << 32) | (unsigned long long)((uint32_t)s->sample & 0x3fffffffu);
+    }
+    key[e] = k;
+    idx[e] = e;
+}
+__global__ __launch_bounds__(256) void k_spill_pixel_keys(SpillLists L, uint32_t m, const unsigned long long* __restrict__ key_sorted,
+                                                          const uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ pixel_key) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= m) return;
+    pixel_key[e] = (key_sorted[e] & SPILL_KEY_INVALID) ? 0xffffffffu : (uint32_t)spill_entry(L, idx_sorted[e])->pixel;
+}
+__global__ __launch_bounds__(256) void k_spill_apply(SpillLists L, uint32_t m, const uint32_t* __restrict__ pixel_sorted, const uint32_t* __restrict__ idx_sorted,
+                                                     float* __restrict__ accum, int width, bool filter, TileOwner own, ForeignSpill* __restrict__ foreign,
+                                                     unsigned long long* counters) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= m) return;
+    const uint32_t gp = pixel_sorted[e];
+    if (gp == 0xffffffffu || (e > 0 && pixel_sorted[e - 1] == gp)) return;  // not the first entry of its pixel
+    const bool mine = !filter || owns_pixel(own, (int)gp, width);
+    float4* px = reinterpret_cast<float4*>(accum) + gp;
+    float4 a = mine ? *px : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t j = e; j < m && pixel_sorted[j] == gp; ++j) {
+        const ForeignSpill s = *spill_entry(L, idx_sorted[j]);
+        if (mine) { a.x += s.r; a.y += s.g; a.z += s.b; a.w += s.w; }
+        else {
+            // a pixel of a block this call does not render: waits in the foreign list for ptgpu_tiles_pack_dev (which sorts again)
             const unsigned long long slot = atomicAdd(&counters[CTR_FOREIGN], 1ull);
-            if (slot < (unsigned long long)FOREIGN_CAPACITY) foreign[slot] = ForeignSpill{s.x, s.y, s.z, 1.0f * scale, gp, 0, 0, 0};
+            if (slot < (unsigned long long)FOREIGN_CAPACITY) foreign[slot] = s;
             else atomicAdd(&counters[CTR_DROPPED], 1ull);
         }
     }
+    if (mine) *px = a;
+}
+// tiles sharded over ranks: every out-of-block sample of the pass goes to the foreign list (all ranks add all of them after the exchange)
+__global__ __launch_bounds__(256) void k_spill_to_foreign(const ForeignSpill* __restrict__ spill, unsigned long long spill_capacity,
+                                                          ForeignSpill* __restrict__ foreign, unsigned long long* counters) {
+    unsigned long long n = counters[CTR_SPILL];
+    if (n > spill_capacity) n = spill_capacity;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * 256ull) {
+        const unsigned long long slot = atomicAdd(&counters[CTR_FOREIGN], 1ull);
+        if (slot < (unsigned long long)FOREIGN_CAPACITY) foreign[slot] = spill[e];
+        else atomicAdd(&counters[CTR_DROPPED], 1ull);
+    }
+}
+
+int ptgpu_apply_spills_sorted(ptgpu_context* c, const SpillLists& lists, float* d_accum, int32_t width, int32_t height, const TileOwner* own) {
+    const long long m64 = (long long)lists.per_list * lists.num_lists;
+    if (m64 <= 0) return PTGPU_OK;
+    if (m64 > SPILL_CAPACITY_MAX * 8) return fail(PTGPU_E_UNSUPPORTED, "%lld out-of-block sample slots to sort", m64);
+    const uint32_t m = (uint32_t)m64;
+    hipStream_t st = c->stream;
+    // workspace: key[m] u64 x2, idx[m] u32 x3, pixel key[m] u32 x2, rocprim temporary storage
+    size_t t1 = 0, t2 = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)m, 0u, 54u, st));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, t2, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)m, 0u, 32u, st));
+    const size_t temp = ((t1 > t2 ? t1 : t2) + 255) & ~(size_t)255, a8 = ((size_t)m * 8 + 255) & ~(size_t)255, a4 = ((size_t)m * 4 + 255) & ~(size_t)255;
+    const size_t need = 2 * a8 + 5 * a4 + temp;
+    if (need > c->sort_ws_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c->d_sort_ws) { HIP_TRY(hipFree(c->d_sort_ws)); c->d_sort_ws = nullptr; c->sort_ws_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_sort_ws, need));
+        c->sort_ws_bytes = need;
+    }
+    unsigned char* w = c->d_sort_ws;
+    unsigned long long *key = (unsigned long long*)w, *key2 = (unsigned long long*)(w + a8);
+    uint32_t *idx = (uint32_t*)(w + 2 * a8), *idx2 = idx + a4 / 4, *idx3 = idx2 + a4 / 4, *pk = idx3 + a4 / 4, *pk2 = pk + a4 / 4;
+    void* tmp = w + 2 * a8 + 5 * a4;
+    const dim3 grid((m + 255u) / 256u), block(256);
+    hipLaunchKernelGGL(k_spill_keys, grid, block, 0, st, lists, m, (int)((long long)width * height), key, idx);
+    size_t tb = temp;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, key, key2, idx, idx2, (size_t)m, 0u, 54u, st));
+    hipLaunchKernelGGL(k_spill_pixel_keys, grid, block, 0, st, lists, m, key2, idx2, pk);
+    tb = temp;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, pk, pk2, idx2, idx3, (size_t)m, 0u, 32u, st));
+    hipLaunchKernelGGL(k_spill_apply, grid, block, 0, st, lists, m, pk2, idx3, d_accum, (int)width, own != nullptr, own ? *own : TileOwner{0, 0, 1, 1},
+                       c->d_foreign, c->d_counters);
+    HIP_TRY(hipGetLastError());
+    return PTGPU_OK;
+}
+
+// Upper bound of the out-of-block samples of one pass of `samples` samples, for sizing the pass's list on the host: a coordinate
+// c = b0 + bw * sobol() lands on b0 + bw when sobol() >= 1 - ulp(c) / (2 bw); ulp(c) <= 2^-11 for images up to 8192 pixels wide, bw = 32
+// except in clipped edge blocks => below 2^-16 per sample for both coordinates together.  Four times that, plus a floor.
+static size_t spill_bound(long long samples) {
+    long long b = (samples >> 14) + 4096;
+    return (size_t)(b > SPILL_CAPACITY_MAX ? SPILL_CAPACITY_MAX : b);
 }
 
 __global__ __launch_bounds__(256) void k_accum_gauss(ptgpu_params prm, ptd::PassDesc pd, const float4* __restrict__ rad, float* __restrict__ accum) {
@@ -1235,6 +1319,18 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     if (rc != PTGPU_OK) return rc;
     rc = ptgpu_ensure_spill_lists(c);
     if (rc != PTGPU_OK) return rc;
+    const int count_all = (block_end - block_begin + block_stride - 1) / block_stride;
+    // this pass's list of out-of-block samples holds `bound` entries (more are counted as dropped)
+    const size_t bound = spill_bound((long long)count_all * 1024LL * prm->num_aa_rays);
+    if (prm->sobol_block) {
+        const size_t want = bound;
+        if (want > c->spill_capacity) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_spill) { HIP_TRY(hipFree(c->d_spill)); c->d_spill = nullptr; c->spill_capacity = 0; }
+            HIP_TRY(hipMalloc(&c->d_spill, want * sizeof(ForeignSpill)));
+            c->spill_capacity = want;
+        }
+    }
     // spill list and dropped-sample count are per pass (all batches of this call append to one list, applied after the last block sum)
     if (prm->sobol_block) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + CTR_SPILL, 2);
     const bool pooled = env_int("PTGPU_PT_POOL", 0) != 0;  // the pooled form of the integrator (csrc/pt_integrator_pool.hip.h), off unless asked for
@@ -1286,16 +1382,26 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
 #undef PT_LAUNCH
         if (rc != PTGPU_OK) return rc;
         if (prm->sobol_block) {
-            hipLaunchKernelGGL(k_accum_sobol, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum, c->d_spill, c->d_counters);
+            hipLaunchKernelGGL(k_accum_sobol, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum, c->d_spill,
+                               (unsigned long long)bound, c->d_counters);
         } else {
             hipLaunchKernelGGL(k_accum_gauss, dim3(pd.num_blocks), dim3(256), 0, c->stream, *prm, pd, c->d_rad, d_accum);
         }
         HIP_TRY(hipGetLastError());
     }
     if (prm->sobol_block) {
-        const TileOwner own{block_begin, block_end, block_stride, blocks_x};
-        hipLaunchKernelGGL(k_apply_spill, dim3(1), dim3(64), 0, c->stream, *prm, own, c->d_spill, d_accum, c->d_foreign, c->d_counters);
-        HIP_TRY(hipGetLastError());
+        // the pass's out-of-block samples, once, after its last block sum
+        if (block_stride > 1) {
+            // tiles sharded over ranks: all of them travel with this rank's tiles and every rank adds every rank's after the exchange
+            hipLaunchKernelGGL(k_spill_to_foreign, dim3((unsigned)((bound + 255) / 256 < 1024 ? (bound + 255) / 256 : 1024)), dim3(256), 0, c->stream,
+                               c->d_spill, (unsigned long long)bound, c->d_foreign, c->d_counters);
+            HIP_TRY(hipGetLastError());
+        } else {
+            const TileOwner own{block_begin, block_end, block_stride, blocks_x};
+            const SpillLists lists{reinterpret_cast<const float4*>(c->d_spill), 0, (int32_t)bound, 1, c->d_counters + CTR_SPILL};
+            rc = ptgpu_apply_spills_sorted(c, lists, d_accum, prm->width, prm->height, &own);
+            if (rc != PTGPU_OK) return rc;
+        }
     }
     return PTGPU_OK;
 }
@@ -1314,7 +1420,6 @@ extern "C" int ptgpu_spill_status(ptgpu_context* c, uint64_t out[3]) {
 }
 
 int ptgpu_ensure_spill_lists(ptgpu_context* c) {
-    if (!c->d_spill) HIP_TRY(hipMalloc(&c->d_spill, sizeof(float4) * SPILL_CAPACITY));
     if (!c->d_foreign) HIP_TRY(hipMalloc(&c->d_foreign, sizeof(ForeignSpill) * FOREIGN_CAPACITY));
     return PTGPU_OK;
 }

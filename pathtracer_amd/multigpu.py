@@ -4,8 +4,9 @@ functions (include/ptgpu.h "image tiles", csrc/pt_multigpu.hip).
 The scene is replicated; the 32x32 blocks of the reference's tiling (src/PathTraceRenderer.cpp:816-841, row-major block index) are
 dealt round-robin: rank r of N renders blocks r, r+N, r+2N, ... (ptgpu_render_pass_dev(block_begin=r, block_stride=N)).  After a
 pass every rank's blocks are exchanged with ONE all-gather; nothing is summed, so the N-GPU image is bit-identical to the 1-GPU one.
-Sobol-block samples that land one pixel outside their block, in a block of another rank, travel in a small fixed section of each
-rank's slice and are added by every rank in rank order (without that they would be overwritten by the owner's tile and lost).
+Sobol-block samples that land one pixel outside their block travel in a fixed section of each rank's slice and are added by every
+rank after the exchange, per pixel in (source block, sample) order -- the order in which a single process adds them (added before
+the exchange they would be overwritten by the owner's tile and lost, or summed in an order that depends on the rank count).
 
   DeviceTileGather  the product path: ptgpu_gather_tiles_dev = pack kernel + ncclAllGather (RCCL over xGMI) + unpack kernels on the
                     context's stream; this class only creates the communicator (id broadcast over torch.distributed).
@@ -19,7 +20,7 @@ import torch.distributed as dist
 
 BLOCK = 32
 TILE_PIXELS = BLOCK * BLOCK
-FOREIGN_CAPACITY = 1024  # csrc/pt_context.h
+FOREIGN_CAPACITY = 65536  # csrc/pt_context.h
 FOREIGN_FLOATS = 4 + FOREIGN_CAPACITY * 8
 
 
@@ -146,11 +147,15 @@ class TileGather:
         for r in range(self.world):
             if r != self.rank:
                 img[self.pix[r]] = r4[r][self.pos[r]]
-        for r in range(self.world):  # every rank's foreign samples, rank order then list order, one at a time
+        # every rank's out-of-block samples, per pixel in (source block, sample) order, one at a time: the order of a single process
+        ents = []
+        for r in range(self.world):
             sec = self.recv.view(self.world, -1)[r][self.tile_f4 * 4:]
             cnt = int(sec[0:1].view(torch.int32)[0])
-            ent = sec[4:4 + cnt * 8].view(cnt, 8)
-            for e in range(cnt):
-                p = int(ent[e, 4:5].view(torch.int32)[0])
-                img[p] += ent[e, :4]
+            ents.append(sec[4:4 + cnt * 8].view(cnt, 8))
+        ent = torch.cat(ents) if ents else self.recv.new_zeros((0, 8))
+        if ent.shape[0]:
+            keys = ent[:, 4:7].contiguous().view(torch.int32).numpy().astype(np.int64)  # pixel, source block, sample
+            for e in np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0])):
+                img[int(keys[e, 0])] += ent[int(e), :4]
         return accum

@@ -1,6 +1,6 @@
 """BASELINE.json configs[3] AS WRITTEN, as far as one GPU can take it: the ~262k-triangle scene (scene.atrium_scene, the procedural
 stand-in for Crytek Sponza, which the reference checkout does not hold) path traced at 3840x2160 with 1024 samples per pixel, and its
-image tiles exchanged between 2, 4 and 8 ranks.
+image tiles exchanged between 2, 4, 7 and 8 ranks.
 
   * twelve 32x32 blocks of the 4K frame at 1024 spp -- centre, columns, floor, ceiling, the clipped bottom row -- bit-exact against
     oracle.render_pass on the same blocks, in both AA modes (reference src/PathTraceRenderer.cpp:706-733 Sobol-block, :734-789 Gaussian;
@@ -8,7 +8,7 @@ image tiles exchanged between 2, 4 and 8 ranks.
   * the whole frame at 1024 spp (8.5 G samples, 33 integrator batches of 256 Mi samples per pass -- the first time the radiance buffer
     is cycled that often) checked through size-independent properties: per-pixel weight, finiteness, run-to-run bits, ray counter;
   * the tile exchange of ptgpu_tiles_pack_dev / ptgpu_tiles_unpack_dev on that frame with 2, 4 and 8 emulated ranks (contexts on one
-    device, the exchange a device copy; slice = 16.6 MB at 8 ranks, 8100 blocks not divisible by 8) plus a forced foreign spill: every
+    device, the exchange a device copy; slice = 18.8 MB at 8 ranks; 7 ranks: 8160 blocks not divisible) plus a forced foreign spill: every
     rank ends with the 1-context image, bit for bit.
 What still needs more than one GPU: the same exchange over RCCL between processes (tests/test_tiles_gpu.py, skipped below 2 devices)."""
 import concurrent.futures as cf
@@ -49,58 +49,87 @@ def _c3_params(sobol_block, seed, spp=SPP):
                              pass_seed=seed)
 
 
-def test_config3_selected_blocks_exact(atrium_gpu, atrium, oracle):
-    """12 blocks x 1024 pixels x 1024 spp = 12.3 M samples (~65 M rays) through 78-node-deep traversals, every accumulated word equal."""
+def test_config3_selected_blocks_exact(gpu_ctx, atrium_gpu, atrium, oracle):
+    """12 blocks x 1024 pixels x 1024 spp = 12.3 M samples (~65 M rays) through 78-node-deep traversals, every accumulated word equal.
+    In Sobol-block mode a few samples per block land one pixel OUTSIDE their block at these coordinates (the position bx + 32 * sobol()
+    rounds up to bx + 32 once bx is in the thousands): the reference adds them to the neighbouring block's pixel (:727-732), the oracle
+    does so at the end of the pass; on the device they wait in the context's list for pixels this call does not render and are
+    delivered by a world-of-one pack / unpack -- the test requires that they exist and that every one arrives."""
     cam, lights = scene.atrium_view(W, H)
     gauss = [(60, 33), (59, 20), (20, 40), (100, 45), (45, 62), (0, BY - 1), (BX - 1, BY - 1)]  # centre, arches, columns, floor, clipped bottom row
     sobol = [(61, 34), (30, 5), (85, 55), (119, 0), (64, BY - 1)]                                # + ceiling, top-right corner
-    for sobol_block, blocks, seed in ((False, gauss, 7), (True, sobol, 8)):
-        prm = _c3_params(sobol_block, seed)
-        g = np.zeros((H, W, 4), np.float32)
-        for (x, y) in blocks:
-            b = y * BX + x
-            g = atrium_gpu.render_pass(prm, cam, lights, accum=g, block_begin=b, block_end=b + 1)
+    nbytes = W * H * 16
+    d = gpu_ctx.malloc(nbytes)
+    one_slice = gpu_ctx.malloc(capi.tiles_slice_floats(W, H, 1) * 4)
+    try:
+        for sobol_block, blocks, seed in ((False, gauss, 7), (True, sobol, 8)):
+            prm = _c3_params(sobol_block, seed)
+            capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, d, 0, nbytes))
+            pending = 0
+            for (x, y) in blocks:
+                b = y * BX + x
+                atrium_gpu.render_pass_dev(prm, cam, lights, d, block_begin=b, block_end=b + 1)
+                st = gpu_ctx.spill_status()
+                assert st["dropped"] == 0
+                pending = st["foreign_pending"]
+            gpu_ctx.tiles_pack_dev(W, H, 1, 0, d, one_slice)
+            gpu_ctx.tiles_unpack_dev(W, H, 1, 0, one_slice, d)
+            gpu_ctx.sync()
+            assert gpu_ctx.spill_status()["foreign_pending"] == 0
+            g = gpu_ctx.d2h(d, (H, W, 4), np.float32)
 
-        def one(xy):
-            b = xy[1] * BX + xy[0]
-            return oracle.render_pass(atrium, prm, cam, lights, nthreads=1, block_begin=b, block_end=b + 1)
-        c = np.zeros((H, W, 4), np.float32)
-        rays = 0
-        with cf.ThreadPoolExecutor(len(blocks)) as ex:  # the oracle call releases the GIL (ctypes): one block per thread
-            for part, ctr in ex.map(one, blocks):
-                c += part  # blocks are disjoint (out-of-block Sobol samples need 32768 spp): adding zeros elsewhere
-                rays += ctr["rays"]
-        pixels = sum(min(32, W - 32 * x) * min(32, H - 32 * y) for x, y in blocks)
-        assert float(c[..., 3].astype(np.float64).sum()) == float(pixels) and np.isfinite(c).all() and c[..., :3].max() > 0.05
-        assert rays > 4.0 * pixels * SPP
-        diff = _bits(g) != _bits(c)
-        assert not diff.any(), "sobol_block=%s: %d of %d accumulation words differ (max abs %.3g)" % (
-            sobol_block, int(diff.sum()), diff.size, float(np.abs(g - c).max()))
+            def one(xy):
+                b = xy[1] * BX + xy[0]
+                return oracle.render_pass(atrium, prm, cam, lights, nthreads=1, block_begin=b, block_end=b + 1)
+            c = np.zeros((H, W, 4), np.float32)
+            rays = 0
+            with cf.ThreadPoolExecutor(len(blocks)) as ex:  # the oracle call releases the GIL (ctypes): one block per thread
+                for part, ctr in ex.map(one, blocks):
+                    c += part  # the blocks are far apart: adding zeros elsewhere
+                    rays += ctr["rays"]
+            pixels = sum(min(32, W - 32 * x) * min(32, H - 32 * y) for x, y in blocks)
+            assert float(c[..., 3].astype(np.float64).sum()) == float(pixels) and np.isfinite(c).all() and c[..., :3].max() > 0.05
+            assert rays > 4.0 * pixels * SPP
+            inside = np.zeros((H, W), bool)
+            for (x, y) in blocks:
+                inside[32 * y:32 * y + 32, 32 * x:32 * x + 32] = True
+            outside = int((c[..., 3][~inside] != 0).sum())  # pixels outside the rendered blocks that received a sample
+            assert (outside > 0 and pending >= outside) if sobol_block else (outside == 0 and pending == 0), (outside, pending)
+            diff = _bits(g) != _bits(c)
+            assert not diff.any(), "sobol_block=%s: %d of %d accumulation words differ (max abs %.3g)" % (
+                sobol_block, int(diff.sum()), diff.size, float(np.abs(g - c).max()))
+    finally:
+        gpu_ctx.free(d)
+        gpu_ctx.free(one_slice)
 
 
 def test_config3_full_frame_properties(gpu_ctx, atrium_gpu):
-    """3840x2160 x 1024 spp = 8.5 G samples per pass, 33 batches of the 4 GiB radiance buffer.  Gaussian mode twice (bit-identical, weight
-    exactly 1 per pixel, colours in [0,1]: reference :780-787), Sobol-block mode once (every sample adds weight 2^-10 to one pixel:
-    the weights sum to the pixel count exactly, reference :727-732)."""
+    """3840x2160 x 1024 spp = 8.5 G samples per pass, 33 batches of the 4 GiB radiance buffer.  Sobol-block mode twice: every sample adds
+    weight 2^-10 to one pixel, so the weights sum to the pixel count exactly (reference :727-732) -- including the tens of thousands of
+    samples per pass that land one pixel outside their block at 4K coordinates, which are added per pixel in (block, sample) order after
+    the block sums: run-to-run bit-identical although they are collected in whatever order the hardware finishes them.  Gaussian
+    mode once: weight exactly 1 per pixel, colours in [0,1] (reference :780-787)."""
     cam, lights = scene.atrium_view(W, H)
     nbytes = W * H * 16
     d = gpu_ctx.malloc(nbytes)
     try:
-        imgs, rays = [], []
-        for sobol_block in (False, False, True):
+        imgs, rays, spilled = [], [], []
+        for sobol_block in (True, True, False):
             capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, d, 0, nbytes))
             gpu_ctx.reset_counters()
             atrium_gpu.render_pass_dev(_c3_params(sobol_block, 3), cam, lights, d)
             gpu_ctx.sync()
             st = gpu_ctx.spill_status()
-            assert st["dropped"] == 0 and (not sobol_block or st["spilled"] == 0)  # out-of-block samples need Sobol indices >= 2^25 - 1: none at 1024 spp
+            assert st["dropped"] == 0 and st["foreign_pending"] == 0
+            spilled.append(st["spilled"])
             rays.append(gpu_ctx.counters()["rays"])
             imgs.append(gpu_ctx.d2h(d, (H, W, 4), np.float32))
     finally:
         gpu_ctx.free(d)
-    a, b, s = imgs
+    s, s2, a = imgs
     samples = W * H * SPP
-    assert np.array_equal(_bits(a), _bits(b)) and rays[0] == rays[1]
+    assert np.array_equal(_bits(s), _bits(s2)) and rays[0] == rays[1] and spilled[0] == spilled[1]
+    assert 5_000 < spilled[0] < 200_000, "out-of-block samples of the pass: %d" % spilled[0]  # ~4e-6 of the samples
     assert np.isfinite(a).all() and (a[..., 3] == 1.0).all() and a[..., :3].min() >= 0.0 and a[..., :3].max() <= 1.0
     assert np.isfinite(s).all() and float(s[..., 3].astype(np.float64).sum()) == float(W * H) and s[..., :3].min() >= 0.0
     assert 0.5 < float(s[..., 3].min()) and float(s[..., 3].max()) < 1.5  # the Sobol points of a block spread evenly over its pixels
@@ -108,7 +137,7 @@ def test_config3_full_frame_properties(gpu_ctx, atrium_gpu):
         assert 4.0 < r / samples < 7.0, "rays per sample %.2f" % (r / samples)
     # the two AA modes are two estimates of the same picture: mean colour within 5 % (Gaussian mode clamps to [0,1], so compare where unclamped)
     dark = (s[..., :3].max(-1) < 0.8) & (a[..., :3].max(-1) < 0.8)
-    assert dark.mean() > 0.5 and abs(float(a[dark][:, :3].mean()) / float(s[dark][:, :3].mean()) - 1.0) < 0.05
+    assert dark.mean() > 0.3 and abs(float(a[dark][:, :3].mean()) / float(s[dark][:, :3].mean()) - 1.0) < 0.05
     assert a[..., :3].mean() > 0.02
 
 
@@ -118,19 +147,23 @@ def _empty_scene():
                 nodes=np.zeros(0, capi.FLATNODE_DTYPE), list=np.zeros(0, np.int32))
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4, 8, 7])
 def test_config3_tile_exchange_with_emulated_ranks(atrium, world):
-    """The 4K frame sharded over `world` ranks (round-robin 32x32 blocks), a Sobol-block and a Gaussian pass, tiles exchanged after each;
-    then a forced foreign spill: blocks 0 .. 2*world-1 at 32768 spp on an empty scene put the Sobol indices whose value is exactly 1.0f
-    into every block, i.e. one sample per block on pixel x = 32 (the next block: another rank's) and one on y = 32 (block +120: beyond
-    this partial pass, nobody's).  Every rank must end with the image ONE context renders, including those samples' weights (2^-15)."""
+    """The 4K frame sharded over `world` ranks (round-robin 32x32 blocks): a Sobol-block and a Gaussian pass over the whole frame, then
+    four rows of blocks (y = 1920 .. 2047) at the full 1024 spp in Sobol-block mode, where some 1,500 samples land one pixel outside
+    their block, dozens of them in a pixel another one lands in; tiles exchanged after each; then a forced spill: blocks
+    0 .. 2*world-1 at 32768 spp on an empty scene put the Sobol indices whose value is exactly 1.0f into every block, i.e. one sample per
+    block on pixel x = 32 (the next block: another rank's) and one on y = 32 (block +120: beyond this partial pass, nobody's).  Every
+    rank must end with the image ONE context renders, bit for bit: out-of-block samples are added per pixel in (block, sample) order
+    whichever rank traced them and in whatever order the lists were filled."""
     cam, lights = scene.atrium_view(W, H)
     nbytes = W * H * 16
-    steps = [("atrium", scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=1, sobol_block=True, pass_seed=1), -1),
-             ("atrium", scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=2, sobol_block=False, filter_width=1.5, pass_seed=2), -1),
-             ("empty", scene.make_params(width=W, height=H, bounces=1, num_aa_rays=32768, sobol_block=True, pass_seed=4), 2 * world)]
+    steps = [("atrium", scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=1, sobol_block=True, pass_seed=1), 0, -1),
+             ("atrium", scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=2, sobol_block=False, filter_width=1.5, pass_seed=2), 0, -1),
+             ("atrium", _c3_params(True, 3), 60 * BX, 64 * BX),
+             ("empty", scene.make_params(width=W, height=H, bounces=1, num_aa_rays=32768, sobol_block=True, pass_seed=4), 0, 2 * world)]
     sf = capi.tiles_slice_floats(W, H, world)
-    assert sf == ((BX * BY + world - 1) // world) * 4096 + 4 + 1024 * 8 and (world != 8 or (BX * BY) % world != 0)
+    assert sf == ((BX * BY + world - 1) // world) * 4096 + 4 + 65536 * 8 and (world != 7 or (BX * BY) % world != 0)  # 7: a ragged last round
     ctxs = [capi.Context(0) for _ in range(world)]
     scenes = [dict(atrium=capi.Scene(c, atrium), empty=capi.Scene(c, _empty_scene())) for c in ctxs]
     try:
@@ -139,9 +172,10 @@ def test_config3_tile_exchange_with_emulated_ranks(atrium, world):
         for c, a in zip(ctxs, acc):
             capi._check(c.lib.ptgpu_memset(c.handle, a, 0, nbytes))
         foreign_seen = 0
-        for which, prm, block_end in steps:
+        for which, prm, block0, block_end in steps:
             for r in range(world):
-                scenes[r][which].render_pass_dev(prm, cam, lights, acc[r], block_begin=r, block_end=block_end, block_stride=world)
+                # rank r owns the blocks b with b % world == r (what pack / unpack move): its first one at or after block0
+                scenes[r][which].render_pass_dev(prm, cam, lights, acc[r], block_begin=block0 + (r - block0) % world, block_end=block_end, block_stride=world)
                 st = ctxs[r].spill_status()
                 assert st["dropped"] == 0
                 foreign_seen += st["foreign_pending"]
@@ -150,13 +184,13 @@ def test_config3_tile_exchange_with_emulated_ranks(atrium, world):
             for r in range(world):
                 ctxs[r].tiles_unpack_dev(W, H, world, r, slices, acc[r])
                 ctxs[r].sync()
-        assert foreign_seen >= 2 * world  # at least the x = 32 sample of every block of the forced pass
+        assert foreign_seen >= 500 + 2 * world  # the 1024-spp rows' out-of-block samples and at least the x = 32 sample of every forced block
         # ONE context, all blocks; its own out-of-range samples of the partial pass are delivered by a world-of-one pack / unpack
         ref = ctxs[0].malloc(nbytes)
         one = ctxs[0].malloc(capi.tiles_slice_floats(W, H, 1) * 4)
         capi._check(ctxs[0].lib.ptgpu_memset(ctxs[0].handle, ref, 0, nbytes))
-        for which, prm, block_end in steps:
-            scenes[0][which].render_pass_dev(prm, cam, lights, ref, block_begin=0, block_end=block_end, block_stride=1)
+        for which, prm, block0, block_end in steps:
+            scenes[0][which].render_pass_dev(prm, cam, lights, ref, block_begin=block0, block_end=block_end, block_stride=1)
             ctxs[0].tiles_pack_dev(W, H, 1, 0, ref, one)
             ctxs[0].tiles_unpack_dev(W, H, 1, 0, one, ref)
         ctxs[0].sync()
@@ -164,7 +198,7 @@ def test_config3_tile_exchange_with_emulated_ranks(atrium, world):
         ctxs[0].free(ref)
         ctxs[0].free(one)
         wsum = float(ref_img[..., 3].astype(np.float64).sum())
-        assert wsum == 2.0 * W * H + 2 * world * 1024.0, wsum  # two full passes + the forced pass's blocks, nothing lost or doubled
+        assert wsum == 2.0 * W * H + 4 * BX * 1024.0 + 2 * world * 1024.0, wsum  # two full passes, four rows, the forced blocks: nothing lost or doubled
         assert ref_img[..., :3].max() > 0.01 and np.isfinite(ref_img).all()
         for r in range(world):
             img = ctxs[r].d2h(acc[r], (H, W, 4), np.float32)
