@@ -17,5 +17,10 @@ run() { # name, rocprofv3 args...
 run trace --kernel-trace --stats &&
 run fetch --pmc FETCH_SIZE &&
 run write --pmc WRITE_SIZE &&
-run l2 --pmc TCC_HIT_sum TCC_MISS_sum
+run l2 --pmc TCC_HIT_sum TCC_MISS_sum &&
+run sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY &&
+run sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE &&
+run tatd --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE &&
+run tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_FLAT_READ_WAVEFRONTS_sum &&
+run utcl1 --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum
 echo "profiles done rc=$?"

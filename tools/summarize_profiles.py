@@ -61,6 +61,28 @@ def main():
     keep = {k: v for k, v in out.items() if k.startswith("k_")}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(keep, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    if len(sys.argv) > 3 and sys.argv[3].startswith("big="):
+        # a large-scene pass (tools/run_profiles_big.sh): its kernels go to profiles/traffic_big.json under the scene's name
+        scene_key = sys.argv[3][4:]
+        path = os.path.join(ROOT, "profiles", "traffic_big.json")
+        big = json.load(open(path)) if os.path.exists(path) else {}
+        fields = ("hbm_bytes_corrected", "hbm_bytes_raw", "l2_hit_rate", "valu_active_frac_of_wave_cycles", "valu_lane_utilisation", "td_busy_frac",
+                  "ta_busy_frac", "avg_duration_us", "launches", "vgpr", "lds_bytes", "TCP_UTCL1_TRANSLATION_MISS_sum", "TCP_UTCL1_TRANSLATION_HIT_sum",
+                  "TCP_UTCL1_REQUEST_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TA_FLAT_READ_WAVEFRONTS_sum")
+        entry = {"source": "profiles/%s_pmc_summary.json: rocprofv3 --pmc passes over tools/bench_bigscenes.py %s (separate runs per counter group; "
+                           "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE KiB per MI355X_MICROARCH.md's gfx950 correction)" % (tag, scene_key)}
+        for k, v in keep.items():
+            if k.startswith("k_raycast_step<false") or k.startswith("k_raycast_step<true") or k.startswith("k_integrate") or k.startswith("k_raycast_persist"):
+                e = {f: v[f] for f in fields if f in v}
+                if "hbm_bytes_corrected" in e:
+                    e["hbm_bytes_per_launch"] = e["hbm_bytes_corrected"]
+                    e["hbm_GBps"] = e["hbm_bytes_corrected"] / (e["avg_duration_us"] * 1e-6) / 1e9 if e.get("avg_duration_us") else None
+                entry[k] = e
+        big[scene_key] = entry
+        json.dump(big, open(path, "w"), indent=1, sort_keys=True)
+        for k, v in sorted(keep.items()):
+            print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
+        return
     # what bench.py reads: one entry per kernel of the bench line's rooflines
     traffic = {}
     want = {"k_raycast_closest": "k_raycast_step<false", "k_raycast_anyhit": "k_raycast_step<true", "k_integrate": "k_integrate",

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B timing of the one-ray-per-lane raycast kernel's LDS stack size on the larger scenes (variants interleaved in ONE process,
-identical hit ids asserted).  Run on the GPU box:  python tools/tune_bigscene.py [atrium|tetra] [tetra_tris] [nlds,nlds,...]"""
+"""A/B timing of the raycast kernels on the larger scenes (variants interleaved in ONE process, identical hit ids asserted): the
+one-ray-per-lane kernel's LDS stack size, or the persistent kernel with refill (impl 2) at a refill threshold and grid oversubscription.
+Run on the GPU box:  python tools/tune_bigscene.py [atrium|tetra] [tetra_tris] [variant,variant,...]   variant = nlds | impl:nlds[:refill[:oversub]]"""
 import os
 import sys
 
@@ -15,7 +16,7 @@ from pathtracer_amd import capi, hostapi, scene  # noqa: E402
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
     ntri = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
-    variants = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "8,12,16,24").split(",")]
+    variants = (sys.argv[3] if len(sys.argv) > 3 else "8,12,16,24").split(",")
     if which == "atrium":
         mesh, view, W, H = scene.atrium_scene(), scene.atrium_view, 3840, 2160
     else:
@@ -46,7 +47,9 @@ def main():
     times = {k: dict(closest=[], anyhit=[]) for k in variants}
     for r in range(6):
         for k in variants:
-            os.environ["PTGPU_RAYCAST_NLDS"] = str(k)
+            f_ = (k.split(":") + ["", "", ""])[:4] if ":" in k else ["1", k, "", ""]
+            os.environ["PTGPU_RAYCAST_IMPL"], os.environ["PTGPU_RAYCAST_NLDS"] = f_[0], f_[1]
+            os.environ["PTGPU_RAYCAST_REFILL"], os.environ["PTGPU_RAYCAST_OVERSUB"] = f_[2] or "32", f_[3] or "1"
             for kind in ("closest", "anyhit"):
                 ev[0].record(stream)
                 if kind == "closest":
@@ -61,7 +64,7 @@ def main():
                     times[k][kind].append(ev[0].elapsed_time(ev[1]))
     print("%s: %d triangles, tree depth %d, %d rays" % (which, mesh["pos"].shape[0], st["true_depth"], n))
     for k in variants:
-        print("nlds %2d  closest ms %.3f  anyhit ms %.3f" % (k, np.median(times[k]["closest"]), np.median(times[k]["anyhit"])), flush=True)
+        print("variant %-12s closest ms %.3f  anyhit ms %.3f" % (k, np.median(times[k]["closest"]), np.median(times[k]["anyhit"])), flush=True)
 
 
 if __name__ == "__main__":
