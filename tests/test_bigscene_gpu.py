@@ -1,8 +1,8 @@
 """GPU parity on the larger BASELINE configurations and on trees deeper than the LDS traversal stack.
 
-configs[3] stand-in: scene.atrium_scene (~262k triangles, procedural: Crytek Sponza is not in the reference checkout); configs[4]
-stand-in: scene.tetra_cloud_scene at 1 M triangles here (the 10 M instance is exercised by tools/bench_bigscenes.py, where the
-same size-independent checks run: hit-record equality against the oracle on a ray sample).  Deep trees: a geometric chain of
+configs[3] stand-in: scene.atrium_scene (~262k triangles, procedural: Crytek Sponza is not in the reference checkout) at small image
+sizes here -- tests/test_config3_gpu.py runs it as written (3840x2160, 1024 spp); configs[4] stand-in: scene.tetra_cloud_scene at
+1 M triangles here -- tests/test_configs_gpu.py::test_config4_ten_million_triangles_dof_exact runs the full 10 M.  Deep trees: a geometric chain of
 triangle clusters whose median-split BVH is 49 levels deep, so every kernel takes its global-memory stack-overflow variant."""
 import numpy as np
 import pytest
