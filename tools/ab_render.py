@@ -46,7 +46,7 @@ def main():
             env = dict(os.environ)
             if n != "base":
                 env["PTGPU_LIB"] = os.path.join(ROOT, "build", "libptgpu_%s.so" % n)
-                if n.startswith("p"):
+                if n.startswith("pool_"):  # a build meant to be run with the pooled integrator (NOT any name in p: "prev" once was)
                     env["PTGPU_PT_POOL"] = "1"
             if n == "pool":
                 env.pop("PTGPU_LIB", None)
