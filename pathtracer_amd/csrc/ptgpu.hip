@@ -282,6 +282,74 @@ static int child_ref(const ptgpu_flatnode* nodes, const std::vector<int32_t>& in
     return nodes[child].leaf ? ~nodes[child].startIdx : inner_index[child];
 }
 
+// Where interior record k (pre-order number) goes in the record array.  The order is this library's choice: only the references inside
+// the records have to follow it.  PTGPU_NODE_ORDER (read at scene creation, an experiment knob; DESIGN.md section 4 has the measurements):
+//   0  depth-first pre-order, the order of the flattened tree (the default)
+//   1  breadth-first
+//   2..6  treelets: the top D = 2..6 levels of a subtree breadth-first in one run, then the subtrees below it, recursively
+//   9  sibling pairs: both interior children of a node in one aligned 128-byte line, subtrees depth-first
+// Returns slot[k]; *n_slots >= n_inner (mode 9 leaves gaps).
+static std::vector<int32_t> interior_slots(const ptgpu_flatnode* nodes, const std::vector<int32_t>& inner_index, int n_inner, int mode, int* n_slots) {
+    std::vector<int32_t> slot(n_inner);
+    *n_slots = n_inner;
+    if (mode <= 0 || n_inner == 0) {
+        for (int k = 0; k < n_inner; ++k) slot[k] = k;
+        return slot;
+    }
+    auto interior_children = [&](int f, int out[2]) {
+        int n = 0;
+        const int kids[2] = {f + 1, nodes[f].rightChild};
+        for (int k = 0; k < 2; ++k)
+            if (!nodes[kids[k]].leaf) out[n++] = kids[k];
+        return n;
+    };
+    int next = 0;
+    if (mode == 1) {
+        std::vector<int> queue{0};
+        for (size_t h = 0; h < queue.size(); ++h) {
+            const int f = queue[h];
+            slot[inner_index[f]] = next++;
+            int kids[2];
+            const int n = interior_children(f, kids);
+            for (int k = 0; k < n; ++k) queue.push_back(kids[k]);
+        }
+    } else if (mode == 9) {
+        slot[inner_index[0]] = 0;
+        next = 2;
+        std::vector<int> stack{0};
+        while (!stack.empty()) {
+            const int f = stack.back();
+            stack.pop_back();
+            int kids[2];
+            const int n = interior_children(f, kids);
+            if (n == 2) next = (next + 1) & ~1;
+            for (int k = 0; k < n; ++k) slot[inner_index[kids[k]]] = next++;
+            for (int k = n - 1; k >= 0; --k) stack.push_back(kids[k]);
+        }
+        *n_slots = next;
+    } else {
+        const int levels = mode;
+        std::vector<int> roots{0}, level, below;
+        while (!roots.empty()) {
+            const int r = roots.back();
+            roots.pop_back();
+            level.assign(1, r);
+            for (int l = 0; l < levels && !level.empty(); ++l) {
+                below.clear();
+                for (int f : level) {
+                    slot[inner_index[f]] = next++;
+                    int kids[2];
+                    const int n = interior_children(f, kids);
+                    for (int k = 0; k < n; ++k) below.push_back(kids[k]);
+                }
+                level.swap(below);
+            }
+            for (size_t k = level.size(); k-- > 0;) roots.push_back(level[k]);  // the subtrees below this treelet, leftmost next
+        }
+    }
+    return slot;
+}
+
 // triangle / material / texture arrays of a scene description (everything but the hierarchy)
 static int check_scene_arrays(const ptgpu_scene_desc* d) {
     const int32_t nn = d->num_nodes, nl = d->list_size, nt = d->num_tris;
@@ -338,6 +406,8 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
     s->num_textures = d->num_textures;
     std::vector<float4> inner, tris;
     int depth = 0;
+    const char* order_env = getenv("PTGPU_NODE_ORDER");
+    const int node_order = order_env ? atoi(order_env) : 0;
     if (nn > 0) {
         if (!d->nodes || !d->list || nl <= 0 || nt <= 0) return fail(PTGPU_E_INVALID, "BVH given without nodes/list/triangles");
         for (int i = 0; i < nl; ++i)
@@ -375,18 +445,22 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
         if (next_list != nl) return fail(PTGPU_E_INVALID, "leaves cover %d of %d list entries", next_list, nl);
         if (depth > 64) return fail(PTGPU_E_UNSUPPORTED, "tree depth %d exceeds 64 (the reference's traversal stack, RayTracer.cpp:190)", depth);
 
-        inner.resize((size_t)n_inner * 4);
+        int n_slots = n_inner;
+        const std::vector<int32_t> slot = interior_slots(d->nodes, inner_index, n_inner, node_order, &n_slots);
+        inner.assign((size_t)n_slots * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         for (int i = 0; i < nn; ++i) {
             if (inner_index[i] < 0) continue;
             const ptgpu_flatnode& n = d->nodes[i];
             const ptgpu_flatnode& L = d->nodes[i + 1];
             const ptgpu_flatnode& R = d->nodes[n.rightChild];
-            float4* o = &inner[(size_t)inner_index[i] * 4];
+            float4* o = &inner[(size_t)slot[inner_index[i]] * 4];
             // x/y planes pairwise, z planes together: the fast slab test runs on packed fp32 pairs (pt_traverse.hip.h)
             o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmax[0], L.bmax[1]);
             o[1] = make_float4(R.bmin[0], R.bmin[1], R.bmax[0], R.bmax[1]);
             o[2] = make_float4(L.bmin[2], L.bmax[2], R.bmin[2], R.bmax[2]);
             int refL = child_ref(d->nodes, inner_index, i + 1), refR = child_ref(d->nodes, inner_index, n.rightChild);
+            if (refL >= 0) refL = slot[refL];
+            if (refR >= 0) refR = slot[refR];
             float fl, fr, fa;
             int32_t ax = n.axis;
             memcpy(&fl, &refL, 4); memcpy(&fr, &refR, 4); memcpy(&fa, &ax, 4);
@@ -425,13 +499,14 @@ static int build_scene(ptgpu_context* c, const ptgpu_scene_desc* d, ptgpu_scene*
     {
         // one array: triangle record p at index (nl - 1 - p), interior record i at index nl + i  (records = base + nl records)
         const size_t n_tri_rec = tris.size() / 4, n_in_rec = inner.size() / 4;
-        std::vector<float4> all((n_tri_rec + n_in_rec) * 4);
-        for (size_t p = 0; p < n_tri_rec; ++p) memcpy(&all[(n_tri_rec - 1 - p) * 4], &tris[p * 4], 64);
-        if (n_in_rec) memcpy(&all[n_tri_rec * 4], inner.data(), n_in_rec * 64);
+        const size_t pad = node_order > 0 ? (n_tri_rec & 1) : 0;  // experimental orders: interior record 0 on a 128-byte line boundary
+        std::vector<float4> all((pad + n_tri_rec + n_in_rec) * 4);
+        for (size_t p = 0; p < n_tri_rec; ++p) memcpy(&all[(pad + n_tri_rec - 1 - p) * 4], &tris[p * 4], 64);
+        if (n_in_rec) memcpy(&all[(pad + n_tri_rec) * 4], inner.data(), n_in_rec * 64);
         if ((rc = upload(c, &s->d_records, all.data(), all.size(), nullptr))) return rc;
         s->bytes[0] += inner.size() * sizeof(float4);
         s->bytes[1] += tris.size() * sizeof(float4);
-        s->trav.records = s->d_records + n_tri_rec * 4;
+        s->trav.records = s->d_records + (pad + n_tri_rec) * 4;
     }
     return upload_shading_arrays(c, d, s);
 }

@@ -58,6 +58,21 @@ def test_head_incoherent(head_gpu, head, oracle, occlusion):
     _assert_same(g, c, "head incoherent")
 
 
+@pytest.mark.parametrize("order", ["1", "3", "9"])
+def test_interior_record_order_does_not_change_results(gpu_ctx, head, oracle, order, monkeypatch):
+    """PTGPU_NODE_ORDER (csrc/ptgpu.hip interior_slots): breadth-first, treelet and sibling-pair placement of the interior records are
+    layouts only -- hits stay bit-exact against the oracle and the traversal counters stay those of the pre-order scene."""
+    monkeypatch.setenv("PTGPU_NODE_ORDER", order)
+    s = capi.Scene(gpu_ctx, head["sd"])
+    monkeypatch.delenv("PTGPU_NODE_ORDER")
+    try:
+        o, d = _random_rays(60000, 23, [-1.4, -0.45, -0.45], [1.4, 0.95, 0.45])
+        for occlusion in (False, True):
+            _assert_same(s.raycast(o, d, occlusion), oracle.raycast(head["sd"], o, d, occlusion, nthreads=8), "order " + order)
+    finally:
+        s.close()
+
+
 @pytest.mark.parametrize("occlusion", [False, True])
 def test_soup_rays(soup_gpu, soup, oracle, occlusion):
     o, d = _random_rays(50000, 5, [-1.5, -1.5, -1.0], [1.5, 1.5, 1.0], length=4.0)
