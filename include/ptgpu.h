@@ -254,11 +254,13 @@ int ptgpu_sobol_sample_batch(ptgpu_context* ctx, int64_t n, const uint64_t* inde
  * pixels pass through undivided.  Both pointers are DEVICE pointers, [height][width][4] floats. */
 int ptgpu_resolve_dev(ptgpu_context* ctx, const float* d_accum, int32_t width, int32_t height, float* d_out_rgba);
 
-/* Out-of-block samples of the LAST Sobol-block pass on this context (a sample whose sobol() coordinate rounds to exactly 1.0f lands one
- * pixel outside its block, src/PathTraceRenderer.cpp:714-728, p = 2^-24 per coordinate): out[0] = how many there were, out[1] = how many
- * were DROPPED because a list was full (0 in any sane render; ptgpu_render_pass reports it as an error, callers of the _dev variant
- * ask here), out[2] = entries waiting in the foreign list (samples that landed in a block of another rank, delivered by
- * ptgpu_gather_tiles_dev / ptgpu_tiles_pack_dev).  Synchronises the context's stream.  Returns PTGPU_E_INTERNAL if the last pass ran the
+/* Out-of-block samples of the Sobol-block passes on this context (a sample whose position bx + bw * sobol() rounds up to bx + bw lands
+ * one pixel outside its block, src/PathTraceRenderer.cpp:714-728: some 30,000 per 1024-spp pass of a 4K frame): out[0] = how many the
+ * LAST pass had, out[1] = how many were DROPPED because a list was full SINCE THE LAST CALL of this function (0 in any sane render: the
+ * pass's own list is sized from its sample count, the list waiting for a tile exchange holds 65,536; the count is cleared once
+ * reported; ptgpu_render_pass reports it as an error, callers of the _dev variant ask here), out[2] = entries waiting for the next
+ * tile exchange (with tiles dealt over ranks every out-of-block sample travels, ptgpu_gather_tiles_dev / ptgpu_tiles_pack_dev).
+ * Synchronises the context's stream.  Returns PTGPU_E_INTERNAL if the last pass ran the
  * experimental pooled integrator (environment PTGPU_PT_POOL=1) and its watchdog ended a launch early. */
 int ptgpu_spill_status(ptgpu_context* ctx, uint64_t out[3]);
 

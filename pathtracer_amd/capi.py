@@ -229,7 +229,8 @@ class Context:
         return dict(rays=c.rays, node_visits=c.node_visits, tri_tests=c.tri_tests)
 
     def spill_status(self):
-        """Out-of-block samples of the last Sobol-block pass: dict(spilled, dropped, foreign_pending)."""
+        """Out-of-block samples: dict(spilled = in the last Sobol-block pass, dropped = lost to a full list since the last call of this
+        method (cleared by it), foreign_pending = waiting for the next tile exchange)."""
         o = (C.c_uint64 * 3)()
         _check(self.lib.ptgpu_spill_status(self.handle, C.byref(o)))
         return dict(spilled=o[0], dropped=o[1], foreign_pending=o[2])

@@ -1406,8 +1406,10 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
             c->spill_capacity = want;
         }
     }
-    // spill list and dropped-sample count are per pass (all batches of this call append to one list, applied after the last block sum)
-    if (prm->sobol_block) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + CTR_SPILL, 2);
+    // the spill list is per pass (all batches of this call append to one list, applied after the last block sum); the dropped-sample
+    // count is NOT: it stands until ptgpu_spill_status / ptgpu_render_pass has reported it, so a full list in pass k of a sequence of
+    // _dev calls cannot go unnoticed
+    if (prm->sobol_block) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + CTR_SPILL, 1);
     const bool pooled = env_int("PTGPU_PT_POOL", 0) != 0;  // the pooled form of the integrator (csrc/pt_integrator_pool.hip.h), off unless asked for
     // the pooled integrator's abort word is per pass too, whichever integrator this pass runs (ptgpu_spill_status reads it after every pass)
     hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + ptd::CTR_POOL_ABORT, 1);
@@ -1488,6 +1490,7 @@ extern "C" int ptgpu_spill_status(ptgpu_context* c, uint64_t out[3]) {
     HIP_TRY(hipMemcpyAsync(h, c->d_counters + CTR_SPILL, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[CTR_FOREIGN - CTR_SPILL] < (unsigned long long)FOREIGN_CAPACITY ? h[CTR_FOREIGN - CTR_SPILL] : FOREIGN_CAPACITY;
+    if (h[1]) hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + CTR_DROPPED, 1);  // reported: start counting anew
     if (h[ptd::CTR_POOL_ABORT - CTR_SPILL] != 0)
         return fail(PTGPU_E_INTERNAL, "the pooled integrator (PTGPU_PT_POOL=1) gave a launch up after a wave waited 2^%d ticks: the pass's image is incomplete",
                     env_int("PTGPU_POOL_WATCHDOG_LOG2", ptd::POOL_WATCHDOG_LOG2) & 63);
@@ -1519,7 +1522,11 @@ extern "C" int ptgpu_render_pass(ptgpu_scene* s, const ptgpu_params* prm, const 
     static_assert(ptd::CTR_POOL_ABORT == CTR_DROPPED + 3, "one copy covers both words");
     HIP_TRY(hipMemcpy(h, c->d_counters + CTR_DROPPED, sizeof h, hipMemcpyDeviceToHost));
     if (h[3]) return fail(PTGPU_E_INTERNAL, "the pooled integrator (PTGPU_PT_POOL=1) gave a launch up (watchdog): the pass's image is incomplete");
-    if (h[0]) return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples of this pass did not fit the spill lists and were dropped", h[0]);
+    if (h[0]) {
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, c->d_counters + CTR_DROPPED, 1);
+        return fail(PTGPU_E_UNSUPPORTED, "%llu out-of-block samples did not fit the spill lists and were dropped (more than %d waiting for one tile exchange?)",
+                    h[0], FOREIGN_CAPACITY);
+    }
     return PTGPU_OK;
 }
 

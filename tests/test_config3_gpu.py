@@ -147,6 +147,49 @@ def _empty_scene():
                 nodes=np.zeros(0, capi.FLATNODE_DTYPE), list=np.zeros(0, np.int32))
 
 
+def test_config3_out_of_block_list_overflow_is_reported_not_silent(gpu_ctx):
+    """A rank that keeps rendering its half of the 4K frame at 1024 spp WITHOUT exchanging tiles fills the 65,536-entry list that waits
+    for the exchange after a handful of passes (~15,000 out-of-block samples each; the scene is empty, positions do not depend on it).
+    The lost samples must show up in ptgpu_spill_status as `dropped` -- in the call after the overflow, whichever pass it happened in --
+    exactly once; an exchange empties the list and the same context renders on with nothing dropped."""
+    sc = capi.Scene(gpu_ctx, _empty_scene())
+    cam, lights = scene.atrium_view(W, H)
+    nbytes = W * H * 16
+    d = gpu_ctx.malloc(nbytes)
+    one = gpu_ctx.malloc(capi.tiles_slice_floats(W, H, 2) * 4)
+    try:
+        capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, d, 0, nbytes))
+        pending, passes = 0, 0
+        while pending < 65536 and passes < 12:
+            sc.render_pass_dev(_c3_params(True, 10 + passes), cam, lights, d, block_begin=0, block_end=-1, block_stride=2)
+            passes += 1
+            if passes == 2:  # asked in between: nothing lost yet
+                st = gpu_ctx.spill_status()
+                assert st["dropped"] == 0 and 5_000 < st["foreign_pending"] < 65536
+            if passes >= 4:  # NOT asked after every pass: a later pass must not wipe an earlier pass's loss
+                pending = 0 if passes % 2 else gpu_ctx.spill_status()["foreign_pending"]
+        assert pending == 65536, "the list never filled in %d passes" % passes
+        # the status call above that first saw the list full reported the loss and cleared it; provoke one more and check both calls
+        sc.render_pass_dev(_c3_params(True, 30), cam, lights, d, block_begin=0, block_end=-1, block_stride=2)
+        sc.render_pass_dev(_c3_params(True, 31), cam, lights, d, block_begin=0, block_end=-1, block_stride=2)
+        st = gpu_ctx.spill_status()
+        assert st["dropped"] > 20_000 and st["foreign_pending"] == 65536, st  # two passes' worth, the first not forgotten
+        assert gpu_ctx.spill_status()["dropped"] == 0  # reported once
+        # the exchange takes the 65,536 entries that fit and empties the list; the context is as good as new
+        gpu_ctx.tiles_pack_dev(W, H, 2, 0, d, one)
+        st = gpu_ctx.spill_status()
+        assert st["foreign_pending"] == 0 and st["dropped"] == 0
+        sc.render_pass_dev(_c3_params(True, 32), cam, lights, d, block_begin=0, block_end=-1, block_stride=2)
+        st = gpu_ctx.spill_status()
+        assert st["dropped"] == 0 and 5_000 < st["foreign_pending"] < 65536
+        gpu_ctx.tiles_pack_dev(W, H, 2, 0, d, one)
+        gpu_ctx.sync()
+    finally:
+        gpu_ctx.free(d)
+        gpu_ctx.free(one)
+        sc.close()
+
+
 @pytest.mark.parametrize("world", [2, 4, 8, 7])
 def test_config3_tile_exchange_with_emulated_ranks(atrium, world):
     """The 4K frame sharded over `world` ranks (round-robin 32x32 blocks): a Sobol-block and a Gaussian pass over the whole frame, then
