@@ -617,8 +617,11 @@ def extra_legs(ctx, stream, dev):
         pt_ms = ev[0].elapsed_time(ev[1])
         rays = ctx.counters()["rays"]
         prof = big.get(key, {})
-        kprof = next((dict(v, source_tag=prof.get("source", "")) for k, v in prof.items() if k.startswith("k_raycast_step<false")), {})
-        rl = roofline("k_raycast_step<closest-hit>, %d primary rays" % n, alg, ms, kprof,
+        # the closest-hit kernel this scene's size selects (csrc/ptgpu.hip launch_raycast): persistent waves with a 12-entry LDS stack
+        # beyond 64 MB of records, one ray per lane below
+        kname = next((k for pre in ("k_raycast_persist<false, false, false, 12", "k_raycast_step<false") for k in prof if k.startswith(pre)), None)
+        kprof = dict(prof[kname], source_tag=prof.get("source", "")) if kname else {}
+        rl = roofline("%s (closest-hit), %d primary rays" % (kname or "raycast kernel", n), alg, ms, kprof,
                       "primary rays of the frame, one launch.  Algorithmic bytes count every lane's 64-byte record although the lanes of a coherent "
                       "wave share records (one fetch serves many lanes), so `achieved` can exceed what any data path moved; what binds is in the "
                       "counters: `td_busy` (texture-data path) and `hbm.frac` (`traffic` / time / 8 TB/s)", COUNTERS_BIG)

@@ -682,7 +682,7 @@ static int ws_defer_list(RcWorkspace& ws, size_t n) {
 
 template <bool ANYHIT, bool ALPHA, bool COUNT, int NLDS, bool OVF>
 static int launch_rc_persist(ptgpu_scene* s, RcWorkspace& ws, const ptd::TravScene& trav, const float* o, const float* d, long long n, int32_t* id, float* t, float* u, float* v,
-                             const int32_t* ray_index = nullptr, long long expected = -1) {
+                             const int32_t* ray_index = nullptr, long long expected = -1, int refill_default = 32) {
     ptgpu_context* c = s->ctx;
     long long want = ((expected >= 0 ? expected : n) + RC_CHUNK - 1) / RC_CHUNK;  // no more waves than chunks
     if (want < 1) want = 1;
@@ -705,7 +705,7 @@ static int launch_rc_persist(ptgpu_scene* s, RcWorkspace& ws, const ptd::TravSce
         if (rc != PTGPU_OK) return rc;
     }
     hipLaunchKernelGGL((k_raycast_persist<ANYHIT, ALPHA, COUNT, NLDS, OVF>), dim3((unsigned)blocks), dim3(RC_BLOCK), 0, c->stream, trav, o, d, n, id, t,
-                       u, v, ws.counters, env_int("PTGPU_RAYCAST_REFILL", 32), ws.stack_ovf, ray_index);
+                       u, v, ws.counters, env_int("PTGPU_RAYCAST_REFILL", refill_default), ws.stack_ovf, ray_index);
     return PTGPU_OK;
 }
 
@@ -722,16 +722,30 @@ static int launch_raycast(ptgpu_scene* s, RcWorkspace& ws, const float* o, const
     // 8: 1.25/1.66, 12: 1.13/1.71, 16: 1.28/1.90, 24: 1.49/2.24; 10M-triangle cloud (depth 29) 8: 3.77/2.27, 12: 2.54/2.28,
     // 16: 2.14/2.03, 24: 2.73/2.56.
     const bool small_scene = s->bytes[0] + s->bytes[1] <= (4u << 20) && need <= 24;
-    const int impl = env_int("PTGPU_RAYCAST_IMPL", 1), nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : (need <= 24 ? 12 : 16));
-    if (nlds != 8 && nlds != 12 && nlds != 16 && nlds != 24)  // the instantiated set: `defer` below must describe the kernel that runs
+    // Scenes far beyond the caches (records > 64 MB): long-lived waves with refill at 16 idle lanes and a SHORT LDS stack (12 entries,
+    // the rest in global memory: 24 waves per CU instead of 20) -- on such scenes a wave of 64 fresh rays waits for its longest one at
+    // 18 % lane utilisation.  Measured, ms closest / any-hit over a 1080p frame, one ray per lane -> this: tetrahedron clouds of 1 M
+    // triangles 1.48 / 1.32 -> 1.30 / 0.95, 3 M 1.77 / 1.63 -> 1.45 / 1.12, 10 M 2.09 / 1.95 -> 1.80 / 1.29; it loses below that size
+    // (300 k cloud 1.04 -> 1.13 closest; 262 k-triangle atrium 1.09 / 1.67 -> 1.74 / 1.77), with 8 or 10 LDS entries (overflow
+    // traffic), with 16 (fewer waves) and with a grid of 2x / 4x the resident waves.  profiles/r03_persist_short_stack.txt.
+    // A fixed workspace (the entry point that allocates nothing) keeps one ray per lane: its overflow region holds 64 workgroups' stacks.
+    const bool large_scene = s->bytes[0] + s->bytes[1] > (64u << 20) && ws.grow != nullptr;
+    const int impl = env_int("PTGPU_RAYCAST_IMPL", large_scene ? 2 : 1);
+    const int nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : (large_scene && impl == 2 ? 12 : (need <= 24 ? 12 : 16)));
+    if (nlds != 8 && nlds != 12 && nlds != 16 && nlds != 24 && !(nlds == 10 && impl == 2))  // the instantiated set: `defer` below must describe the kernel that runs
         return fail(PTGPU_E_INVALID, "PTGPU_RAYCAST_NLDS=%d: the LDS stack is built with 8, 12, 16 or 24 entries", nlds);
+    const int refill = large_scene ? 16 : 32;
     if constexpr (COUNT || ALPHA) {  // rare variants: one configuration that is valid for every depth
         return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, ws, trav, o, d, n, id, t, u, v);
     } else {
         if (impl == 2) {
-            if (need > 24 || (need > 16 && nlds == 16)) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, ws, trav, o, d, n, id, t, u, v);
-            return nlds == 16 ? launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, false>(s, ws, trav, o, d, n, id, t, u, v)
-                              : launch_rc_persist<ANYHIT, ALPHA, COUNT, 24, false>(s, ws, trav, o, d, n, id, t, u, v);
+            // short LDS stacks with global-memory overflow: more resident waves (12: the default of scenes beyond the caches; 8 / 10: A/B only)
+            if (nlds == 8) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 8, true>(s, ws, trav, o, d, n, id, t, u, v, nullptr, -1, refill);
+            if (nlds == 10) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 10, true>(s, ws, trav, o, d, n, id, t, u, v, nullptr, -1, refill);
+            if (nlds == 12) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 12, true>(s, ws, trav, o, d, n, id, t, u, v, nullptr, -1, refill);
+            if (need > 24 || (need > 16 && nlds == 16)) return launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, true>(s, ws, trav, o, d, n, id, t, u, v, nullptr, -1, refill);
+            return nlds == 16 ? launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, false>(s, ws, trav, o, d, n, id, t, u, v, nullptr, -1, refill)
+                              : launch_rc_persist<ANYHIT, ALPHA, COUNT, 24, false>(s, ws, trav, o, d, n, id, t, u, v, nullptr, -1, refill);
         }
         // one ray per lane.  If the tree could need more stack than the LDS holds, rays that actually do are deferred to a
         // second, persistent launch with global-memory overflow (they are rare: occupancy stays < 16 for almost every ray).
