@@ -626,6 +626,7 @@ def extra_legs(ctx, stream, dev):
                       "wave share records (one fetch serves many lanes), so `achieved` can exceed what any data path moved; what binds is in the "
                       "counters: `td_busy` (texture-data path) and `hbm.frac` (`traffic` / time / 8 TB/s)", COUNTERS_BIG)
         out.append({"workload": name, "triangles": int(m["pos"].shape[0]), "bvh_nodes": int(nodes.shape[0]), "host_sah_build_s": build_s,
+                    "ray_length_probe": s.ray_length(),
                     "primary_Mrays_per_s": n / (ms * 1e-3) / 1e6, "primary_ms": ms,
                     "per_ray": {"nodes": c["node_visits"] / n, "tris": c["tri_tests"] / n, "bytes": alg / n},
                     "primary_algorithmic_GBps": alg / (ms * 1e-3) / 1e9, "roofline": rl,

@@ -159,6 +159,13 @@ int ptgpu_scene_create(ptgpu_context* ctx, const ptgpu_scene_desc* desc, ptgpu_s
 int ptgpu_scene_destroy(ptgpu_scene* scene);
 /* bytes of device memory held by the scene: [0] interior nodes, [1] triangle records, [2] shading attributes, [3] textures */
 int ptgpu_scene_stats(const ptgpu_scene* scene, uint64_t out_bytes[4], int32_t* out_depth);
+/* How long this scene's rays are, and what the path-trace passes derive from it.  No counterpart in the reference (its worker threads
+ * have no such scheduling): before a scene's first pass the library traces 8,192 random rays inside the scene's box (fixed seed, counter
+ * words of their own: ptgpu_get_counters does not see them) and picks from their mean node visits + triangle tests per ray the number
+ * of lanes of a wave that must wait for shading before the wave stops traversing to serve them (32 for short rays, down to 12 for
+ * long ones).  Scheduling only: results do not depend on it.  This call runs the probe if no pass has yet
+ * (synchronises the context's stream then) and returns both numbers; either pointer may be NULL. */
+int ptgpu_scene_ray_length(ptgpu_scene* scene, float* out_steps_per_ray, int32_t* out_service_threshold);
 
 /* ---- RayTracer::raycast(orig, dir, occlusion) (src/RayTracer.cpp:174-290), n rays per call.
  * orig/dir: [n][3] floats (Vec3f arrays); the traced segment is [orig, orig+dir].  use_alpha = RayTracer::useAlpha.

@@ -91,6 +91,7 @@ SIGNATURES = [
     ("ptgpu_scene_create_lbvh", C.c_int, [_P, C.POINTER(SceneDesc), C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     ("ptgpu_scene_destroy", C.c_int, [_P]),
     ("ptgpu_scene_stats", C.c_int, [_P, C.POINTER(C.c_uint64 * 4), C.POINTER(C.c_int32)]),
+    ("ptgpu_scene_ray_length", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     ("ptgpu_raycast_batch", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
     ("ptgpu_raycast_batch_dev", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
     ("ptgpu_raycast_batch_dev_noalloc", C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
@@ -365,6 +366,12 @@ class Scene:
         b, d = (C.c_uint64 * 4)(), C.c_int32()
         _check(self.lib.ptgpu_scene_stats(self.handle, C.byref(b), C.byref(d)))
         return dict(inner_bytes=b[0], tri_bytes=b[1], shading_bytes=b[2], texture_bytes=b[3], depth=d.value)
+
+    def ray_length(self):
+        """dict(steps_per_ray, service_threshold): the scene probe behind the path-trace passes' scheduling (include/ptgpu.h)."""
+        st, thr = C.c_float(), C.c_int32()
+        _check(self.lib.ptgpu_scene_ray_length(self.handle, C.byref(st), C.byref(thr)))
+        return dict(steps_per_ray=st.value, service_threshold=thr.value)
 
     def raycast(self, orig, direction, occlusion=False, use_alpha=True, want=("id", "t", "u", "v")):
         """Host-pointer RayTracer::raycast batch. Returns dict of numpy arrays."""

@@ -61,6 +61,10 @@ struct ptgpu_scene {
     std::vector<uint8_t*> d_texels;
     int32_t num_materials = 0, num_textures = 0;
     uint64_t bytes[4] = {0, 0, 0, 0};
+    // scene_probe (before the scene's first path-trace pass): traversal steps per ray of random rays inside the scene's box, and the
+    // integrator's service threshold chosen from it
+    float probe_steps = -1.0f;
+    int32_t pt_service = 32;
 };
 
 // zero a few counter words with plain stores (the form measured to be visible to a later kernel's atomics on this stream)
@@ -766,6 +770,74 @@ static int launch_raycast(ptgpu_scene* s, RcWorkspace& ws, const float* o, const
     }
 }
 
+// How long are this scene's rays?  8,192 random rays inside the root box (fixed seed), traced once with the counting variant into
+// counter words of their own: node visits + triangle tests per ray.  The integrator's service threshold -- how many lanes must wait
+// for a hit block / new-sample block before the wave stops stepping to run it -- trades the block's instructions (cheaper per lane the
+// more lanes take part) against the steps the waiting lanes sit out, and the best value follows the ray length: measured per 16-spp
+// pass, head.obj (15 steps per probe ray) 32: 19.6 ms, 24: 20.2, 16: 20.9, 12: 22.1; atrium (58) 32: 377, 16: 345, 12: 340, 8: 347;
+// tetrahedron clouds 20 k (87) 32: 42.5, 16: 39.9, 12: 40.1; 1 M (150) 32: 114.6, 12: 102.8; 10 M 32: 163.3, 12: 143.2, 8: 142.4.
+// Scheduling never changes a result (tests/test_render_gpu.py sweeps it).  One small launch and one synchronisation per scene.
+static int scene_probe(ptgpu_scene* s) {
+    if (s->probe_steps >= 0.0f) return PTGPU_OK;
+    ptgpu_context* c = s->ctx;
+    s->probe_steps = 0.0f;
+    s->pt_service = 32;
+    if (s->trav.list_size <= 0) return PTGPU_OK;
+    constexpr int N = 8192;
+    std::vector<float> h((size_t)N * 6);
+    uint32_t x = 0x9E3779B9u;
+    auto rnd = [&x]() { x = x * 1664525u + 1013904223u; return (float)(x >> 8) * (1.0f / 16777216.0f); };
+    float ext[3], diag2 = 0.0f;
+    for (int k = 0; k < 3; ++k) { ext[k] = s->trav.root_bmax[k] - s->trav.root_bmin[k]; diag2 += ext[k] * ext[k]; }
+    const float diag = sqrtf(diag2);
+    for (int i = 0; i < N; ++i) {
+        float d[3], l2;
+        do {
+            l2 = 0.0f;
+            for (int k = 0; k < 3; ++k) { d[k] = 2.0f * rnd() - 1.0f; l2 += d[k] * d[k]; }
+        } while (l2 > 1.0f || l2 < 1e-4f);
+        const float sc = diag / sqrtf(l2);
+        for (int k = 0; k < 3; ++k) {
+            h[(size_t)i * 3 + k] = s->trav.root_bmin[k] + rnd() * ext[k];
+            h[(size_t)N * 3 + (size_t)i * 3 + k] = d[k] * sc;
+        }
+    }
+    unsigned char* d_tmp = nullptr;
+    const size_t ray_bytes = h.size() * sizeof(float), ctr_bytes = (size_t)(CTR_WORDS + RAY_SPREAD) * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc(&d_tmp, ray_bytes + ctr_bytes));
+    float* d_rays = reinterpret_cast<float*>(d_tmp);
+    unsigned long long* d_ctr = reinterpret_cast<unsigned long long*>(d_tmp + ray_bytes);
+    int rc = PTGPU_OK;
+    unsigned long long hc[3] = {0, 0, 0};
+    hipError_t e = hipMemcpyAsync(d_rays, h.data(), ray_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ctr, 0, ctr_bytes, c->stream);
+    if (e == hipSuccess) {
+        RcWorkspace ws{c, d_ctr, c->d_defer, c->defer_capacity, c->d_stack_ovf, c->stack_ovf_bytes, 0};
+        rc = launch_raycast<false, false, true>(s, ws, d_rays, d_rays + (size_t)N * 3, N, nullptr, nullptr, nullptr, nullptr);
+        if (rc == PTGPU_OK) e = hipMemcpyAsync(hc, d_ctr, sizeof hc, hipMemcpyDeviceToHost, c->stream);
+    }
+    const hipError_t e2 = hipStreamSynchronize(c->stream);  // also before the buffer is freed
+    hipFree(d_tmp);
+    if (rc != PTGPU_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return fail(PTGPU_E_HIP, "scene probe failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    s->probe_steps = (float)((double)(hc[1] + hc[2]) / N);
+    // 32 up to 20 steps per ray, 12 from 55 on, linear in between, in steps of 4
+    float t = 32.0f - (s->probe_steps - 20.0f) * (20.0f / 35.0f);
+    t = t > 32.0f ? 32.0f : (t < 12.0f ? 12.0f : t);
+    s->pt_service = ((int)(t + 2.0f) / 4) * 4;
+    return PTGPU_OK;
+}
+
+extern "C" int ptgpu_scene_ray_length(ptgpu_scene* s, float* out_steps_per_ray, int32_t* out_service_threshold) {
+    if (!s) return fail(PTGPU_E_INVALID, "scene is NULL");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    const int rc = scene_probe(s);
+    if (rc != PTGPU_OK) return rc;
+    if (out_steps_per_ray) *out_steps_per_ray = s->probe_steps;
+    if (out_service_threshold) *out_service_threshold = s->pt_service;
+    return PTGPU_OK;
+}
+
 static int raycast_dispatch(ptgpu_scene* s, RcWorkspace& ws, bool alpha, bool count, const float* d_orig, const float* d_dir, int64_t n, int occlusion,
                             int32_t* d_id, float* d_t, float* d_u, float* d_v) {
     int rc;
@@ -1364,7 +1436,7 @@ static int launch_integrate(ptgpu_scene* s, const ptd::TravScene& trav, const pt
         if (rc != PTGPU_OK) return rc;
     }
     hipLaunchKernelGGL((k_integrate<COUNT, NLDS, OVF, ALPHA, EXT>), dim3((unsigned)blocks), dim3(PT_BLOCK), (size_t)env_int("PTGPU_PT_EXTRA_LDS", 0), c->stream, trav, ss, *prm, *cam, c->d_lights, pd, rad ? rad : c->d_rad,
-                       c->d_counters, env_int("PTGPU_PT_SERVICE", 32) | (env_int("PTGPU_PT_CTLMIN", 16) << 8), c->d_stack_ovf);
+                       c->d_counters, (env_int("PTGPU_PT_SERVICE", s->pt_service) & 0xff) | (env_int("PTGPU_PT_CTLMIN", 16) << 8), c->d_stack_ovf);
     return PTGPU_OK;
 }
 
@@ -1407,6 +1479,8 @@ extern "C" int ptgpu_render_pass_dev(ptgpu_scene* s, const ptgpu_params* prm, co
     rc = upload_lights(c, lights, num_lights);
     if (rc != PTGPU_OK) return rc;
     rc = ptgpu_ensure_spill_lists(c);
+    if (rc != PTGPU_OK) return rc;
+    rc = scene_probe(s);  // first pass on this scene only
     if (rc != PTGPU_OK) return rc;
     const int count_all = (block_end - block_begin + block_stride - 1) / block_stride;
     // this pass's list of out-of-block samples holds `bound` entries (more are counted as dropped)

@@ -64,6 +64,8 @@ def test_atrium_rays_and_render_exact(gpu_ctx, atrium, oracle):
         cimg, _ = oracle.render_pass(sd, prm, cam, lights, nthreads=8)
         assert cimg[..., :3].max() > 0.01
         assert np.array_equal(g.view(np.uint32), cimg.view(np.uint32)), "atrium render differs"
+        rl = s.ray_length()  # long rays (58 steps per probe ray): the pass above ran with the low service threshold
+        assert 40.0 < rl["steps_per_ray"] < 80.0 and rl["service_threshold"] == 12, rl
     finally:
         s.close()
 

@@ -86,6 +86,30 @@ def test_head_sobol_block_rr_exact(gpu_ctx, head_gpu, head, oracle):
     assert rays == ctr["rays"], "ray counter %d != oracle %d" % (rays, ctr["rays"])
 
 
+def test_scheduling_knobs_never_change_the_image(gpu_ctx, head_gpu, head, oracle, monkeypatch):
+    """The integrator's service threshold (how many lanes wait for shading before the wave serves them) is chosen per scene from a
+    ray-length probe, and the control section's entry count is a second knob: whatever their values, every sample is the same sample.
+    The probe's rays go to counter words of their own."""
+    w, h = 96, 64
+    prm = scene.make_params(width=w, height=h, bounces=-1, num_aa_rays=3, sobol_block=True, pass_seed=6)
+    cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]
+    c, ctr = oracle.render_pass(head["sd"], prm, cam, lights, nthreads=8)
+    fresh = capi.Scene(gpu_ctx, head["sd"])  # a scene that has not been probed yet
+    try:
+        gpu_ctx.reset_counters()
+        g = fresh.render_pass(prm, cam, lights)  # runs the probe first
+        assert gpu_ctx.counters()["rays"] == ctr["rays"], "the probe's rays leaked into the public counter"
+        _assert_image_exact(g, c, "first pass on a fresh scene")
+        rl = fresh.ray_length()
+        assert 10.0 < rl["steps_per_ray"] < 25.0 and rl["service_threshold"] == 32  # head.obj: short rays (15 steps)
+    finally:
+        fresh.close()
+    for service, ctlmin in ((1, 1), (12, 16), (64, 16), (24, 4), (200, 64)):
+        monkeypatch.setenv("PTGPU_PT_SERVICE", str(service))
+        monkeypatch.setenv("PTGPU_PT_CTLMIN", str(ctlmin))
+        _assert_image_exact(head_gpu.render_pass(prm, cam, lights), c, "service %d, control minimum %d" % (service, ctlmin))
+
+
 def test_head_two_passes_accumulate(head_gpu, head, oracle):
     w, h = 64, 64
     cam, lights = scene.make_camera(width=w, height=h), [scene.make_light()]

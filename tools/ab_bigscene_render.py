@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of one path-trace pass on the larger scenes under environment knobs of the library (read at every launch), variants
 interleaved in ONE process, accumulation images compared bit for bit with the first variant's.
-python tools/ab_bigscene_render.py [atrium|tetra] [spp] "NAME=ENV1=V1;ENV2=V2,NAME2=..."   e.g.  "base=,pool=PTGPU_PT_POOL=1" """
+python tools/ab_bigscene_render.py [atrium|tetra] [spp] "NAME=ENV1=V1;ENV2=V2,NAME2=..." [tetra_tris]   e.g.  "base=,pool=PTGPU_PT_POOL=1" """
 import os
 import sys
 
@@ -23,7 +23,7 @@ def main():
     if which == "atrium":
         mesh, view, W, H, dof = scene.atrium_scene(), scene.atrium_view, 3840, 2160, False
     else:
-        mesh, view, W, H, dof = scene.tetra_cloud_scene(10_000_000), scene.tetra_cloud_view, 1920, 1080, True
+        mesh, view, W, H, dof = scene.tetra_cloud_scene(int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000), scene.tetra_cloud_view, 1920, 1080, True
     nodes, lst, st = hostapi.bvh_build(mesh["pos"], True)
     sd = dict(pos=mesh["pos"], nrm=mesh["nrm"], uv=mesh["uv"], mat_id=mesh["mat_id"], woop=hostapi.woop_from_positions(mesh["pos"]),
               materials=mesh["materials"], textures=[], nodes=nodes, list=lst)
