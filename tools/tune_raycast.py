@@ -49,6 +49,8 @@ def main():
     torch.cuda.synchronize()
     ref_rid = rid.clone()
     variants = [(1, 24, 0, 1), (1, 16, 0, 1), (1, 12, 0, 1), (1, 8, 0, 1), (2, 24, 32, 1)]
+    if len(sys.argv) > 2:  # "impl:nlds:refill:oversub,..."
+        variants = [tuple(int(x) for x in v.split(":")) for v in sys.argv[2].split(",")]
     times = {vv: dict(closest=[], anyhit=[], random=[]) for vv in variants}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for r in range(rounds + 1):
