@@ -1015,11 +1015,14 @@ __global__ void k_gen_shadow(const float* __restrict__ nrm, const uint2* __restr
 // for the four launches (and 0.321 ms for two launches, one per phase, that re-read the hit record: most of the gain is a wave going
 // straight from its primary rays to its shadow rays).  Per-wave ray counts go to spread counter words (RAY_SPREAD).
 // ------------------------------------------------------------------------------------------------
-template <int NLDS, int TILE_W>
+// OVF: the tree may need more than NLDS stack entries; each workgroup (= wave) then owns ovf_entries x 64 entries of stack_ovf, where
+// ovf_entries = tree depth - 1 - NLDS is all a lane can ever push beyond the LDS part.
+template <int NLDS, int TILE_W, bool OVF = false>
 __global__ __launch_bounds__(64) void k_trace_frame(ptd::TravScene S, const float* __restrict__ nrm, const uint2* __restrict__ sobol_pairs, ptgpu_camera cam,
                                                           ptgpu_light L, int width, int height, int tiles_x, int32_t* __restrict__ out_id,
                                                           float* __restrict__ out_t, float* __restrict__ out_u, float* __restrict__ out_v,
-                                                          int32_t* __restrict__ out_shadow_id, unsigned long long* counters) {
+                                                          int32_t* __restrict__ out_shadow_id, unsigned long long* counters,
+                                                          uint2* stack_ovf = nullptr, int ovf_entries = 0) {
     __shared__ uint2 lds_stack[NLDS][64];
     constexpr int TILE_H = 64 / TILE_W;
     const int lane = threadIdx.x;
@@ -1027,9 +1030,9 @@ __global__ __launch_bounds__(64) void k_trace_frame(ptd::TravScene S, const floa
     const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
     const bool have = px < width && py < height;
     const long long i = (long long)py * width + px;
-    ptd::Trav<false, false, NLDS, false, false> tr;
+    ptd::Trav<false, false, NLDS, OVF, false> tr;
     tr.reset_counts();
-    tr.attach(&lds_stack[0][lane], nullptr);
+    tr.attach(&lds_stack[0][lane], OVF ? stack_ovf + (size_t)blockIdx.x * (size_t)ovf_entries * 64 + lane : nullptr);
     tr.alive = false;
     ptd::F3 Ro = ptd::f3(0, 0, 0), Rd = Ro;
     if (have) {
@@ -1063,9 +1066,6 @@ extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, co
     if (!d_id || !d_t || !d_u || !d_v) return fail(PTGPU_E_INVALID, "the primary hit record arrays are required");
     if (width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "image size %dx%d", width, height);
     ptgpu_context* c = s->ctx;
-    if (s->depth - 1 > 24)
-        return fail(PTGPU_E_UNSUPPORTED, "ptgpu_trace_frame_dev: tree depth %d needs more than the 24 LDS stack entries of these kernels; use "
-                    "ptgpu_gen_primary_dev / ptgpu_raycast_batch_dev / ptgpu_gen_shadow_dev", s->depth);
     HIP_TRY(hipSetDevice(c->device));
     ptd::TravScene trav = s->trav;
     trav.alpha_on = 0;
@@ -1075,9 +1075,26 @@ extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, co
     const int th = 64 / tw;
     const int tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
     const dim3 grid((unsigned)(tiles_x * tiles_y));
+    // LDS stack entries per lane.  16 + the rest of the stack (tree depth - 1 - 16 entries, usually a handful) in a global-memory region
+    // per workgroup: 20 resident waves per CU instead of the 13 that 24 entries allow -- the 1080p head frame 0.258 -> 0.247 ms
+    // (12 / 10 / 8 entries: 0.247 / 0.245 / 0.246, for more overflow memory), and no limit on the tree's depth.  PTGPU_FRAME_NLDS=24
+    // and the other tile widths select the all-LDS form (trees up to depth 25) for A/B timing.
+    const int fn = env_int("PTGPU_FRAME_NLDS", 16);
+    if (fn != 16 && fn != 24) return fail(PTGPU_E_INVALID, "PTGPU_FRAME_NLDS=%d: the frame kernel is built with 16 or 24 LDS stack entries", fn);
 #define PT_FRAME(TW) hipLaunchKernelGGL((k_trace_frame<24, TW>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width, \
                                         (int)height, tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters)
-    if (tw == 4) PT_FRAME(4); else if (tw == 16) PT_FRAME(16); else if (tw == 32) PT_FRAME(32); else if (tw == 64) PT_FRAME(64); else PT_FRAME(8);
+    if (fn == 16 && tw == 8) {
+        const int ovf_entries = s->depth - 1 > 16 ? s->depth - 1 - 16 : 0;
+        const int rc = ensure_stack_overflow(c, (size_t)grid.x * (size_t)(ovf_entries > 0 ? ovf_entries : 1) * 64 * sizeof(uint2));
+        if (rc != PTGPU_OK) return rc;
+        hipLaunchKernelGGL((k_trace_frame<16, 8, true>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width,
+                           (int)height, tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters, c->d_stack_ovf, ovf_entries);
+    } else {
+        if (s->depth - 1 > 24)
+            return fail(PTGPU_E_UNSUPPORTED, "ptgpu_trace_frame_dev: tree depth %d needs more than the 24 LDS stack entries of the all-LDS frame kernels "
+                        "(PTGPU_FRAME_NLDS / PTGPU_FRAME_TILE_W select them)", s->depth);
+        if (tw == 4) PT_FRAME(4); else if (tw == 16) PT_FRAME(16); else if (tw == 32) PT_FRAME(32); else if (tw == 64) PT_FRAME(64); else PT_FRAME(8);
+    }
 #undef PT_FRAME
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;

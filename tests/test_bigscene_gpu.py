@@ -141,5 +141,24 @@ def test_deep_tree_uses_stack_overflow_exact(gpu_ctx, oracle, sah):
         cimg, ctr = oracle.render_pass(sd, prm, cam, lights, nthreads=8)
         assert ctr["rays"] > w * h * 4 * 1.3 and cimg[..., :3].max() > 0
         assert np.array_equal(g.view(np.uint32), cimg.view(np.uint32)), "deep-tree render differs"
+        # the one-launch frame on the same tree: its 16 LDS stack entries overflow into the per-workgroup global region
+        # (depth - 17 entries per lane); primary and shadow hits against the oracle's
+        fw, fh = 200, 120
+        n = fw * fh
+        fo, fd = oracle.gen_primary(cam, fw, fh)
+        c = oracle.raycast(sd, fo, fd, False, nthreads=8)
+        so, sdir, valid = oracle.gen_shadow(sd, lights[0], fo, fd, c)
+        cs = oracle.raycast(sd, so, sdir, True, nthreads=8)
+        bufs = [gpu_ctx.malloc(n * 4) for _ in range(5)]
+        try:
+            s.trace_frame_dev(cam, lights[0], fw, fh, *bufs)
+            got_id, got_t = gpu_ctx.d2h(bufs[0], n, np.int32), gpu_ctx.d2h(bufs[1], n, np.uint32)
+            got_sid = gpu_ctx.d2h(bufs[4], n, np.int32)
+        finally:
+            for b in bufs:
+                gpu_ctx.free(b)
+        assert (c["id"] >= 0).mean() > 0.05
+        assert np.array_equal(got_id, c["id"]) and np.array_equal(got_t, c["t"].view(np.uint32))
+        assert np.array_equal(got_sid, np.where(valid == 1, cs["id"], -1))
     finally:
         s.close()

@@ -247,7 +247,9 @@ def test_trace_frame_equals_the_four_launch_sequence(gpu_ctx, head_gpu, size, mo
     hits = int((want["id"] >= 0).sum())
     assert gpu_ctx.counters()["rays"] == 2 * n and hits > n // 10  # the separate form also "traces" the empty rays of missed pixels
     f_id, f_t, f_u, f_v, f_sid = (gpu_ctx.malloc(n * 4) for _ in range(5))
-    for tile_w in ("8",):
+    for tile_w, nlds in (("8", "16"), ("8", "24"), ("16", "24")):  # the default (16 LDS entries + overflow region) and the all-LDS forms
+        monkeypatch.setenv("PTGPU_FRAME_TILE_W", tile_w)
+        monkeypatch.setenv("PTGPU_FRAME_NLDS", nlds)
         for p in (f_id, f_t, f_u, f_v, f_sid):
             capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, p, 0xEE, n * 4))
         gpu_ctx.reset_counters()
