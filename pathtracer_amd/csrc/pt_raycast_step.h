@@ -14,10 +14,15 @@ namespace ptd {
 // any-hit 0.188 vs 0.236 ms, incoherent 0.296 vs 0.375 ms.
 constexpr int RC_STEP_BLOCK = 64;
 
-// Launches k_raycast_step<anyhit, no alpha, no counting, nlds, defer> over n rays on `stream`; nlds is 8, 12, 16 or (anything else) 24.
-// defer: rays whose stack outgrows the LDS entries are appended to defer_list (count in counters[5]) instead of being traced.
-__attribute__((visibility("hidden"))) void launch_raycast_step(bool anyhit, int nlds, bool defer, hipStream_t stream, const TravScene& trav,
+// What a lane does when its stack outgrows the nlds LDS entries:
+//   RC_BEYOND_NEVER     the tree is shallow enough that it cannot happen
+//   RC_BEYOND_DEFER     the ray is appended to defer_list (count in counters[5]) instead of being traced (k_raycast_persist's overflow variant takes it)
+//   RC_BEYOND_OVERFLOW  deeper entries live in stack_ovf: ovf_entries x 64 entries of 8 bytes per workgroup of the grid (ceil(n / 64) of them)
+constexpr int RC_BEYOND_NEVER = 0, RC_BEYOND_DEFER = 1, RC_BEYOND_OVERFLOW = 2;
+// Launches k_raycast_step<anyhit, no alpha, no counting, nlds, ...> over n rays on `stream`; nlds is 8, 12, 16 or (anything else) 24.
+__attribute__((visibility("hidden"))) void launch_raycast_step(bool anyhit, int nlds, int beyond, hipStream_t stream, const TravScene& trav,
                                                                const float* o, const float* d, long long n, int32_t* id, float* t, float* u,
-                                                               float* v, unsigned long long* counters, int32_t* defer_list);
+                                                               float* v, unsigned long long* counters, int32_t* defer_list, uint2* stack_ovf,
+                                                               int ovf_entries);
 
 }  // namespace ptd

@@ -720,11 +720,13 @@ static int launch_raycast(ptgpu_scene* s, RcWorkspace& ws, const float* o, const
     trav.alpha_on = ALPHA ? 1 : 0;
     // stack occupancy <= depth - 1 (one far sibling per ancestor level); the counting variant pushes every far child as well
     const int need = s->depth - 1;
-    // LDS stack entries per lane.  24 (13 waves/CU, never overflows up to depth 25) wins while the tree sits in one XCD's L2.  Once
-    // fetches leave L2 more waves win, and rays whose stack outgrows the LDS are deferred: about half the tree depth keeps them rare.
-    // Measured closest / any-hit frames, ms: head (depth 21) 24: 0.147/0.181, 16: 0.154/0.177; 262k-triangle atrium (depth 24)
-    // 8: 1.25/1.66, 12: 1.13/1.71, 16: 1.28/1.90, 24: 1.49/2.24; 10M-triangle cloud (depth 29) 8: 3.77/2.27, 12: 2.54/2.28,
-    // 16: 2.14/2.03, 24: 2.73/2.56.
+    // LDS stack entries per lane: fewer entries = more resident waves (64 lanes x 8 B per entry).  A lane whose stack outgrows them
+    // either continues in a global-memory region of its workgroup (growable workspace, RC_BEYOND_OVERFLOW) or is deferred to a second,
+    // persistent launch (fixed workspace, RC_BEYOND_DEFER).  Measured closest / any-hit frames, ms (round 3, overflow regions):
+    // head (1.6 MB, depth 22, coherent camera rays) 24: 0.136 / 0.174, 16: 0.146 / 0.164, 12: 0.144 / 0.166, 8: 0.144 / 0.168 (its
+    // random rays 0.274 / 0.238 / 0.218 / 0.208); 262k-triangle atrium (33 MB, depth 24) 8: 1.05 / 1.52, 12: 1.07 / 1.57, 16: 1.20 / 1.80,
+    // 24: 1.44 / 2.17; clouds of 50 k triangles 8: 0.53 / 0.63, 24: 0.66 / 0.80; 300 k 8: 0.95 / 0.92, 12: 0.98 / 0.96, 16: 1.08 / 1.05.
+    // With deferral (what the fixed workspace still does) 12 entries were best up to depth 25, 16 beyond (8 defers too many rays).
     const bool small_scene = s->bytes[0] + s->bytes[1] <= (4u << 20) && need <= 24;
     // Scenes far beyond the caches (records > 64 MB): long-lived waves with refill at 16 idle lanes and a SHORT LDS stack (12 entries,
     // the rest in global memory: 24 waves per CU instead of 20) -- on such scenes a wave of 64 fresh rays waits for its longest one at
@@ -735,7 +737,16 @@ static int launch_raycast(ptgpu_scene* s, RcWorkspace& ws, const float* o, const
     // A fixed workspace (the entry point that allocates nothing) keeps one ray per lane: its overflow region holds 64 workgroups' stacks.
     const bool large_scene = s->bytes[0] + s->bytes[1] > (64u << 20) && ws.grow != nullptr;
     const int impl = env_int("PTGPU_RAYCAST_IMPL", large_scene ? 2 : 1);
-    const int nlds = env_int("PTGPU_RAYCAST_NLDS", small_scene ? 24 : (large_scene && impl == 2 ? 12 : (need <= 24 ? 12 : 16)));
+    const size_t groups = (size_t)((n + RC_STEP_BLOCK - 1) / RC_STEP_BLOCK);
+    auto region_bytes = [&](int entries) { return need > entries ? groups * (size_t)(need - entries) * 64 * sizeof(uint2) : (size_t)0; };
+    const size_t region_cap = (size_t)1 << 30;  // of the context's grow-only overflow buffer
+    const bool regions = ws.grow != nullptr && env_int("PTGPU_RAYCAST_DEFER", 0) == 0;
+    int nlds_default;
+    if (large_scene && impl == 2) nlds_default = 12;
+    else if (small_scene) nlds_default = (ANYHIT && regions && region_bytes(16) <= region_cap) ? 16 : 24;
+    else if (regions && region_bytes(8) <= region_cap) nlds_default = 8;
+    else nlds_default = need <= 24 ? 12 : 16;
+    const int nlds = env_int("PTGPU_RAYCAST_NLDS", nlds_default);
     if (nlds != 8 && nlds != 12 && nlds != 16 && nlds != 24 && !(nlds == 10 && impl == 2))  // the instantiated set: `defer` below must describe the kernel that runs
         return fail(PTGPU_E_INVALID, "PTGPU_RAYCAST_NLDS=%d: the LDS stack is built with 8, 12, 16 or 24 entries", nlds);
     const int refill = large_scene ? 16 : 32;
@@ -751,16 +762,25 @@ static int launch_raycast(ptgpu_scene* s, RcWorkspace& ws, const float* o, const
             return nlds == 16 ? launch_rc_persist<ANYHIT, ALPHA, COUNT, 16, false>(s, ws, trav, o, d, n, id, t, u, v, nullptr, -1, refill)
                               : launch_rc_persist<ANYHIT, ALPHA, COUNT, 24, false>(s, ws, trav, o, d, n, id, t, u, v, nullptr, -1, refill);
         }
-        // one ray per lane.  If the tree could need more stack than the LDS holds, rays that actually do are deferred to a
-        // second, persistent launch with global-memory overflow (they are rare: occupancy stays < 16 for almost every ray).
-        const bool defer = need > nlds;
+        // one ray per lane.  If the tree could need more stack than the LDS holds: with a growable workspace every workgroup of the grid
+        // gets a global-memory region for its deeper entries (need - nlds entries x 512 B per 64 rays; at most 1 GiB, else as below);
+        // with the fixed workspace of the entry point that allocates nothing the rays that actually overflow are deferred to a second,
+        // persistent launch whose bounded set of waves owns overflow regions (they are rare: occupancy stays < 16 for almost every ray).
+        int beyond = need > nlds ? ptd::RC_BEYOND_DEFER : ptd::RC_BEYOND_NEVER;
+        const size_t ovf_bytes = region_bytes(nlds);
+        if (beyond == ptd::RC_BEYOND_DEFER && regions && ovf_bytes <= region_cap) {
+            const int rc = ws_stack_overflow(ws, ovf_bytes);
+            if (rc != PTGPU_OK) return rc;
+            beyond = ptd::RC_BEYOND_OVERFLOW;
+        }
+        const bool defer = beyond == ptd::RC_BEYOND_DEFER;
         if (defer) {
             if (n > 0x7fffffffLL) return fail(PTGPU_E_INVALID, "n too large for the deferred-ray list");
             const int rc = ws_defer_list(ws, (size_t)n);
             if (rc != PTGPU_OK) return rc;
             hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, c->stream, ws.counters + 5, 1);
         }
-        ptd::launch_raycast_step(ANYHIT, nlds, defer, c->stream, trav, o, d, n, id, t, u, v, ws.counters, ws.defer);
+        ptd::launch_raycast_step(ANYHIT, nlds, beyond, c->stream, trav, o, d, n, id, t, u, v, ws.counters, ws.defer, ws.stack_ovf, need - nlds);
         if (defer) {
             // the number of deferred rays is only known on the device: a small fixed grid, the kernel reads the count itself
             const long long expected = n / 64 < 65536 ? 65536 : n / 64;
@@ -770,13 +790,6 @@ static int launch_raycast(ptgpu_scene* s, RcWorkspace& ws, const float* o, const
     }
 }
 
-// How long are this scene's rays?  8,192 random rays inside the root box (fixed seed), traced once with the counting variant into
-// counter words of their own: node visits + triangle tests per ray.  The integrator's service threshold -- how many lanes must wait
-// for a hit block / new-sample block before the wave stops stepping to run it -- trades the block's instructions (cheaper per lane the
-// more lanes take part) against the steps the waiting lanes sit out, and the best value follows the ray length: measured per 16-spp
-// pass, head.obj (15 steps per probe ray) 32: 19.6 ms, 24: 20.2, 16: 20.9, 12: 22.1; atrium (58) 32: 377, 16: 345, 12: 340, 8: 347;
-// tetrahedron clouds 20 k (87) 32: 42.5, 16: 39.9, 12: 40.1; 1 M (150) 32: 114.6, 12: 102.8; 10 M 32: 163.3, 12: 143.2, 8: 142.4.
-// Scheduling never changes a result (tests/test_render_gpu.py sweeps it).  One small launch and one synchronisation per scene.
 static int scene_probe(ptgpu_scene* s) {
     if (s->probe_steps >= 0.0f) return PTGPU_OK;
     ptgpu_context* c = s->ctx;
