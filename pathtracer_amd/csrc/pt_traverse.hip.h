@@ -128,14 +128,14 @@ struct LaneStack {
         const unsigned long long e = ((unsigned long long)__float_as_uint(tentry) << 32) | (unsigned long long)(uint32_t)ref;
         if (DEFER) {
             if (sp < NLDS) lds[sp * 64] = e; else full = true;
-        } else if (!OVF || sp < NLDS) lds[sp * 64] = e;
+        } else if (!OVF || __builtin_expect(sp < NLDS, 1)) lds[sp * 64] = e;
         else gl[(sp - NLDS) * 64] = e;
         ++sp;
     }
     __device__ __forceinline__ uint2 pop() {
         --sp;
         unsigned long long e;
-        if (!OVF || sp < NLDS) e = lds[sp * 64];
+        if (!OVF || __builtin_expect(sp < NLDS, 1)) e = lds[sp * 64];
         else e = gl[(sp - NLDS) * 64];
         return make_uint2((uint32_t)e, (uint32_t)(e >> 32));
     }
