@@ -1096,9 +1096,15 @@ extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, co
     if (fn != 16 && fn != 24) return fail(PTGPU_E_INVALID, "PTGPU_FRAME_NLDS=%d: the frame kernel is built with 16 or 24 LDS stack entries", fn);
 #define PT_FRAME(TW) hipLaunchKernelGGL((k_trace_frame<24, TW>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width, \
                                         (int)height, tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters)
-    if (fn == 16 && tw == 8) {
-        const int ovf_entries = s->depth - 1 > 16 ? s->depth - 1 - 16 : 0;
-        const int rc = ensure_stack_overflow(c, (size_t)grid.x * (size_t)(ovf_entries > 0 ? ovf_entries : 1) * 64 * sizeof(uint2));
+    const int ovf_entries = s->depth - 1 > 16 ? s->depth - 1 - 16 : 0;
+    const size_t ovf_bytes = (size_t)grid.x * (size_t)(ovf_entries > 0 ? ovf_entries : 1) * 64 * sizeof(uint2);
+    // the overflow buffer is grow-only: beyond 4 GiB (an 8K frame on a 40-level tree) the all-LDS form takes over where the tree allows it
+    const bool regions_fit = ovf_bytes <= ((size_t)4 << 30);
+    if (fn == 16 && tw == 8 && !regions_fit && s->depth - 1 > 24)
+        return fail(PTGPU_E_UNSUPPORTED, "ptgpu_trace_frame_dev: a %dx%d frame on a tree of depth %d needs %zu bytes of stack overflow regions; use "
+                    "ptgpu_gen_primary_dev / ptgpu_raycast_batch_dev / ptgpu_gen_shadow_dev", width, height, s->depth, ovf_bytes);
+    if (fn == 16 && tw == 8 && regions_fit) {
+        const int rc = ensure_stack_overflow(c, ovf_bytes);
         if (rc != PTGPU_OK) return rc;
         hipLaunchKernelGGL((k_trace_frame<16, 8, true>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width,
                            (int)height, tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters, c->d_stack_ovf, ovf_entries);
