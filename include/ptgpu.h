@@ -203,7 +203,8 @@ int ptgpu_gen_shadow_dev(ptgpu_scene* scene, const ptgpu_light* light, int64_t n
  * [height*width] indexed by pixel: the primary hit record (d_id, d_t, d_u, d_v as ptgpu_raycast_batch_dev writes them; required) and
  * the occluder the shadow ray found (d_shadow_id: -1 = none or no primary hit; NULL = primary rays only); bit-identical to the
  * four-call sequence.  Alpha cutout is not applied.  Any tree depth the scene accepts (<= 64): stack entries beyond the 16 kept in LDS go
- * to a grow-only device buffer of the context ((tree depth - 17) x 512 bytes per 8x8 pixel tile, allocated by the first such call). */
+ * to a grow-only device buffer of the context ((tree depth - 17) x 512 bytes per 8x8 pixel tile, allocated by the first such call; beyond
+ * 4 GiB of it a kernel with all 24 entries in LDS runs instead, or, on trees deeper than 25 levels, PTGPU_E_UNSUPPORTED is returned). */
 int ptgpu_trace_frame_dev(ptgpu_scene* scene, const ptgpu_camera* cam, const ptgpu_light* light, int32_t width, int32_t height, int32_t* d_id,
                           float* d_t, float* d_u, float* d_v, int32_t* d_shadow_id);
 
