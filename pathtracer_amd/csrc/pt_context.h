@@ -93,6 +93,7 @@ struct ptgpu_context {
     size_t defer_capacity = 0;
     uint2* d_stack_ovf = nullptr;  // global-memory overflow of the per-lane traversal stacks (trees deeper than the LDS stack)
     size_t stack_ovf_bytes = 0;
+    const uint32_t* d_sobol_matrices = nullptr;  // device address of ptd::g_sobol_matrices on this device
     uint2* d_sobol_pairs = nullptr;  // byte-indexed Sobol table for the integrator (pt_integrator.hip.h sobol32x2), built at init
     unsigned char* d_stage = nullptr;  // grow-only device staging of the host-pointer entry points (rays in, hit records out, images)
     size_t stage_bytes = 0;

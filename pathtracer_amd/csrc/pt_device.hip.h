@@ -60,6 +60,27 @@ __device__ __forceinline__ float sobol_sample(unsigned long long index, unsigned
     return (float)result * (1.f / 4294967296.f);
 }
 
+// two consecutive dimensions (dimension even) of one index -- the reference always draws them in pairs.  The low 24 index bits go
+// through the byte table (ptgpu.hip k_build_sobol_pairs), any higher bits through sobol::sample's bit loop over `matrices`
+// (= g_sobol_matrices; a parameter so that a translation unit other than the one defining the table can pass its address in).
+__device__ __forceinline__ void sobol32x2m(const uint2* __restrict__ tab, const uint32_t* __restrict__ matrices, uint32_t index, unsigned dimension,
+                                           float& a, float& b) {
+    const uint2* t = tab + (size_t)(dimension >> 1) * 768;
+    const uint2 e0 = t[index & 255u], e1 = t[256u + ((index >> 8) & 255u)], e2 = t[512u + ((index >> 16) & 255u)];
+    unsigned ra = e0.x ^ e1.x ^ e2.x, rb = e0.y ^ e1.y ^ e2.y;
+    index >>= 24;
+    if (index) {
+        const uint32_t* row = matrices + dimension * 52u + 24u;
+        for (unsigned i = 0; index; index >>= 1, ++i) {
+            uint32_t m = 0u - (index & 1u);
+            ra ^= row[i] & m;
+            rb ^= row[i + 52] & m;
+        }
+    }
+    a = (float)ra * (1.f / 4294967296.f);
+    b = (float)rb * (1.f / 4294967296.f);
+}
+
 // ---- stand-in for FW::Random (absent from the reference's tree): counter-based, one stream per sample ----
 struct Rng {
     uint32_t key, ctr;

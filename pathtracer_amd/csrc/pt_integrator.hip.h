@@ -140,20 +140,7 @@ __device__ __forceinline__ float sobol32(uint32_t index, unsigned dimension) {
 // through the byte table (ptgpu.hip k_build_sobol_pairs), any higher bits through sobol::sample's bit loop.
 constexpr int SOBOL_PAIRS = 512;
 __device__ __forceinline__ void sobol32x2(const uint2* __restrict__ tab, uint32_t index, unsigned dimension, float& a, float& b) {
-    const uint2* t = tab + (size_t)(dimension >> 1) * 768;
-    const uint2 e0 = t[index & 255u], e1 = t[256u + ((index >> 8) & 255u)], e2 = t[512u + ((index >> 16) & 255u)];
-    unsigned ra = e0.x ^ e1.x ^ e2.x, rb = e0.y ^ e1.y ^ e2.y;
-    index >>= 24;
-    if (index) {
-        const uint32_t* row = g_sobol_matrices + dimension * 52u + 24u;
-        for (unsigned i = 0; index; index >>= 1, ++i) {
-            uint32_t m = 0u - (index & 1u);
-            ra ^= row[i] & m;
-            rb ^= row[i + 52] & m;
-        }
-    }
-    a = (float)ra * (1.f / 4294967296.f);
-    b = (float)rb * (1.f / 4294967296.f);
+    sobol32x2m(tab, g_sobol_matrices, index, dimension, a, b);
 }
 
 __device__ __forceinline__ F3 light_col(const ptgpu_light& l, int c) { return f3(l.xform[c * 4], l.xform[c * 4 + 1], l.xform[c * 4 + 2]); }

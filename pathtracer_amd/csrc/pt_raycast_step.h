@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/ptgpu.h"
 #include "pt_traverse.hip.h"
 
 namespace ptd {
@@ -24,5 +25,13 @@ __attribute__((visibility("hidden"))) void launch_raycast_step(bool anyhit, int 
                                                                const float* o, const float* d, long long n, int32_t* id, float* t, float* u,
                                                                float* v, unsigned long long* counters, int32_t* defer_list, uint2* stack_ovf,
                                                                int ovf_entries);
+
+// The configs[1] frame in one launch (k_trace_frame): with_regions = 16 LDS stack entries + ovf_entries x 64 entries of stack_ovf per
+// workgroup (8x8 tiles); otherwise all 24 entries in LDS (trees up to depth 25) and tiles tile_w pixels wide.  grid = one workgroup per tile.
+__attribute__((visibility("hidden"))) void launch_trace_frame(hipStream_t stream, dim3 grid, bool with_regions, int tile_w, const TravScene& trav,
+                                                              const float* nrm, const uint2* sobol_pairs, const uint32_t* sobol_matrices,
+                                                              const ptgpu_camera& cam, const ptgpu_light& light, int width, int height, int tiles_x,
+                                                              int32_t* id, float* t, float* u, float* v, int32_t* shadow_id,
+                                                              unsigned long long* counters, uint2* stack_ovf, int ovf_entries);
 
 }  // namespace ptd

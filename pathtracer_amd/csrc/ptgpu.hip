@@ -14,6 +14,7 @@
 #include "pt_context.h"
 #include "pt_traverse.hip.h"
 #include "pt_raycast_step.h"
+#include "pt_frame_rays.hip.h"
 #include "pt_integrator.hip.h"
 #include "pt_integrator_pool.hip.h"
 #include "pt_lbvh.hip.h"
@@ -103,6 +104,12 @@ static int init_context(ptgpu_context* c, const hipDeviceProp_t& prop) {
     const int entries = ptd::SOBOL_PAIRS * 3 * 256;
     HIP_TRY(hipMalloc(&c->d_sobol_pairs, (size_t)entries * sizeof(uint2)));
     hipLaunchKernelGGL(k_build_sobol_pairs, dim3((entries + 255) / 256), dim3(256), 0, c->stream, c->d_sobol_pairs);
+    // this device's address of the Sobol matrices, for kernels of other translation units (pt_raycast_step.hip: the frame kernel)
+    {
+        void* sym = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(ptd::g_sobol_matrices)));
+        c->d_sobol_matrices = static_cast<const uint32_t*>(sym);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     {   // ptgpu_cancel's stream: highest priority, so that its one-wave kernel is not queued behind the pass it cancels
@@ -962,16 +969,7 @@ extern "C" int ptgpu_raycast_batch(ptgpu_scene* s, int use_alpha, const float* o
     return PTGPU_OK;
 }
 
-// ---- ray generators for BASELINE config 2 ----
-__device__ __forceinline__ void camera_ray_nodof(const ptgpu_camera& cam, float x, float y, ptd::F3& Ro, ptd::F3& Rd) {
-    ptd::F4 a = ptd::mul44(cam.invP, x, y, 0.0f, 1.0f);
-    float ia = 1.0f / a.w;
-    Ro = ptd::f3(a.x * ia, a.y * ia, a.z * ia);
-    ptd::F4 b = ptd::mul44(cam.invP, x, y, 1.0f, 1.0f);
-    float ib = 1.0f / b.w;
-    Rd = ptd::f3(b.x * ib, b.y * ib, b.z * ib) - Ro;
-}
-
+// ---- ray generators for BASELINE config 2 (camera_ray_nodof, shadow_ray: pt_frame_rays.hip.h) ----
 __global__ void k_gen_primary(ptgpu_camera cam, int width, int height, float* __restrict__ orig, float* __restrict__ dir) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)width * height) return;
@@ -986,25 +984,6 @@ __global__ void k_gen_primary(ptgpu_camera cam, int width, int height, float* __
     dir[i * 3] = Rd.x; dir[i * 3 + 1] = Rd.y; dir[i * 3 + 2] = Rd.z;
 }
 
-// shadow ray of BASELINE configs[1] for the hit (tri, t, u, v) of ray (ro, rd) number i: reference src/PathTraceRenderer.cpp:338-344 towards
-// the Sobol light point with index i, dimensions 4 and 5
-// (the two Sobol values come from the byte-indexed pair table: three independent loads instead of up to 2 x 31 dependent trips of
-// sobol::sample's bit loop -- the same words, XOR being associative; i < 2^31)
-__device__ __forceinline__ void shadow_ray(const float* __restrict__ nrm, const uint2* __restrict__ sobol_pairs, const ptgpu_light& L, unsigned long long i,
-                                           ptd::F3 ro, ptd::F3 rd, int tri, float t, float uu, float vv, ptd::F3& o, ptd::F3& d) {
-    ptd::F3 O = ro + t * rd;
-    const float* nn = nrm + (size_t)tri * 9;
-    ptd::F3 N = ptd::normalize((1 - uu - vv) * ptd::ld3(nn) + uu * ptd::ld3(nn + 3) + vv * ptd::ld3(nn + 6));
-    float sa, sb;
-    ptd::sobol32x2(sobol_pairs, (uint32_t)i, 4u, sa, sb);
-    float x = (2.0f * sa - 1.0f) * L.size[0];
-    float y = (2.0f * sb - 1.0f) * L.size[1];
-    ptd::F3 Pl = ptd::f3(L.xform[12], L.xform[13], L.xform[14]) + ptd::f3(L.xform[0], L.xform[1], L.xform[2]) * x +
-                 ptd::f3(L.xform[4], L.xform[5], L.xform[6]) * y;
-    o = O + 0.0001f * N;
-    d = Pl - O;
-}
-
 __global__ void k_gen_shadow(const float* __restrict__ nrm, const uint2* __restrict__ sobol_pairs, int num_tris, ptgpu_light L, long long n, const float* __restrict__ orig,
                              const float* __restrict__ dir, const int32_t* __restrict__ id, const float* __restrict__ t,
                              const float* __restrict__ u, const float* __restrict__ v, float* __restrict__ so, float* __restrict__ sd,
@@ -1014,63 +993,10 @@ __global__ void k_gen_shadow(const float* __restrict__ nrm, const uint2* __restr
     int tri = id[i];
     ptd::F3 o = ptd::f3(0, 0, 0), d = ptd::f3(0, 0, 0);
     if (tri >= num_tris) tri = -1;  // never index past the scene with a caller-supplied id
-    if (tri >= 0) shadow_ray(nrm, sobol_pairs, L, (unsigned long long)i, ptd::ld3(orig + i * 3), ptd::ld3(dir + i * 3), tri, t[i], u[i], v[i], o, d);
+    if (tri >= 0) shadow_ray(nrm, sobol_pairs, ptd::g_sobol_matrices, L, (unsigned long long)i, ptd::ld3(orig + i * 3), ptd::ld3(dir + i * 3), tri, t[i], u[i], v[i], o, d);
     valid[i] = tri >= 0 ? 1 : 0;
     so[i * 3] = o.x; so[i * 3 + 1] = o.y; so[i * 3 + 2] = o.z;
     sd[i * 3] = d.x; sd[i * 3 + 1] = d.y; sd[i * 3 + 2] = d.z;
-}
-
-// ------------------------------------------------------------------------------------------------
-// BASELINE configs[1] in ONE launch: per pixel the primary ray of k_gen_primary traced closest-hit and, where it hits, the shadow ray of
-// k_gen_shadow traced any-hit -- the rays live in registers, never in HBM (the four-launch form writes and reads 2 x 24 B of ray per
-// pixel and phase and pays three kernel boundaries).  Same device functions, same arithmetic: every output equals the
-// gen_primary -> raycast -> gen_shadow -> raycast sequence bit for bit.  Measured on the 1080p head frame: 0.262 ms against 0.332 ms
-// for the four launches (and 0.321 ms for two launches, one per phase, that re-read the hit record: most of the gain is a wave going
-// straight from its primary rays to its shadow rays).  Per-wave ray counts go to spread counter words (RAY_SPREAD).
-// ------------------------------------------------------------------------------------------------
-// OVF: the tree may need more than NLDS stack entries; each workgroup (= wave) then owns ovf_entries x 64 entries of stack_ovf, where
-// ovf_entries = tree depth - 1 - NLDS is all a lane can ever push beyond the LDS part.
-template <int NLDS, int TILE_W, bool OVF = false>
-__global__ __launch_bounds__(64) void k_trace_frame(ptd::TravScene S, const float* __restrict__ nrm, const uint2* __restrict__ sobol_pairs, ptgpu_camera cam,
-                                                          ptgpu_light L, int width, int height, int tiles_x, int32_t* __restrict__ out_id,
-                                                          float* __restrict__ out_t, float* __restrict__ out_u, float* __restrict__ out_v,
-                                                          int32_t* __restrict__ out_shadow_id, unsigned long long* counters,
-                                                          uint2* stack_ovf = nullptr, int ovf_entries = 0) {
-    __shared__ uint2 lds_stack[NLDS][64];
-    constexpr int TILE_H = 64 / TILE_W;
-    const int lane = threadIdx.x;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int px = tx * TILE_W + (lane % TILE_W), py = ty * TILE_H + (lane / TILE_W);
-    const bool have = px < width && py < height;
-    const long long i = (long long)py * width + px;
-    ptd::Trav<false, false, NLDS, OVF, false> tr;
-    tr.reset_counts();
-    tr.attach(&lds_stack[0][lane], OVF ? stack_ovf + (size_t)blockIdx.x * (size_t)ovf_entries * 64 + lane : nullptr);
-    tr.alive = false;
-    ptd::F3 Ro = ptd::f3(0, 0, 0), Rd = Ro;
-    if (have) {
-        const float div_x = 1.0f / (float)width, div_y = 1.0f / (float)height;
-        const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-        camera_ray_nodof(cam, fx * div_x * 2.0f - 1.0f, fy * div_y * -2.0f + 1.0f, Ro, Rd);
-        tr.begin(S, Ro, Rd, false);
-    }
-    while (tr.alive) tr.step(S);
-    ptd::HitRec h;
-    h.id = -1; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f;
-    if (have) {
-        h = tr.result(S);
-        out_id[i] = h.id; out_t[i] = h.t; out_u[i] = h.u; out_v[i] = h.v;
-    }
-    const bool shadow = have && h.id >= 0 && out_shadow_id;
-    if (shadow) {
-        ptd::F3 so, sd;
-        shadow_ray(nrm, sobol_pairs, L, (unsigned long long)i, Ro, Rd, h.id, h.t, h.u, h.v, so, sd);
-        tr.begin(S, so, sd, true);
-    }
-    while (tr.alive) tr.step(S);
-    if (have && out_shadow_id) out_shadow_id[i] = shadow ? tr.result(S).id : -1;
-    const unsigned long long rays = (unsigned long long)__popcll(__ballot(have)) + (unsigned long long)__popcll(__ballot(shadow));
-    if (lane == 0 && rays) atomicAdd(&counters[CTR_WORDS + (blockIdx.x & (RAY_SPREAD - 1))], rays);
 }
 
 extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, const ptgpu_light* light, int32_t width, int32_t height, int32_t* d_id,
@@ -1094,8 +1020,6 @@ extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, co
     // and the other tile widths select the all-LDS form (trees up to depth 25) for A/B timing.
     const int fn = env_int("PTGPU_FRAME_NLDS", 16);
     if (fn != 16 && fn != 24) return fail(PTGPU_E_INVALID, "PTGPU_FRAME_NLDS=%d: the frame kernel is built with 16 or 24 LDS stack entries", fn);
-#define PT_FRAME(TW) hipLaunchKernelGGL((k_trace_frame<24, TW>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width, \
-                                        (int)height, tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters)
     const int ovf_entries = s->depth - 1 > 16 ? s->depth - 1 - 16 : 0;
     const size_t ovf_bytes = (size_t)grid.x * (size_t)(ovf_entries > 0 ? ovf_entries : 1) * 64 * sizeof(uint2);
     // the overflow buffer is grow-only: beyond 4 GiB (an 8K frame on a 40-level tree) the all-LDS form takes over where the tree allows it
@@ -1103,18 +1027,16 @@ extern "C" int ptgpu_trace_frame_dev(ptgpu_scene* s, const ptgpu_camera* cam, co
     if (fn == 16 && tw == 8 && !regions_fit && s->depth - 1 > 24)
         return fail(PTGPU_E_UNSUPPORTED, "ptgpu_trace_frame_dev: a %dx%d frame on a tree of depth %d needs %zu bytes of stack overflow regions; use "
                     "ptgpu_gen_primary_dev / ptgpu_raycast_batch_dev / ptgpu_gen_shadow_dev", width, height, s->depth, ovf_bytes);
-    if (fn == 16 && tw == 8 && regions_fit) {
+    const bool with_regions = fn == 16 && tw == 8 && regions_fit;
+    if (with_regions) {
         const int rc = ensure_stack_overflow(c, ovf_bytes);
         if (rc != PTGPU_OK) return rc;
-        hipLaunchKernelGGL((k_trace_frame<16, 8, true>), grid, dim3(64), 0, c->stream, trav, s->d_nrm, c->d_sobol_pairs, *cam, *light, (int)width,
-                           (int)height, tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters, c->d_stack_ovf, ovf_entries);
-    } else {
-        if (s->depth - 1 > 24)
-            return fail(PTGPU_E_UNSUPPORTED, "ptgpu_trace_frame_dev: tree depth %d needs more than the 24 LDS stack entries of the all-LDS frame kernels "
-                        "(PTGPU_FRAME_NLDS / PTGPU_FRAME_TILE_W select them)", s->depth);
-        if (tw == 4) PT_FRAME(4); else if (tw == 16) PT_FRAME(16); else if (tw == 32) PT_FRAME(32); else if (tw == 64) PT_FRAME(64); else PT_FRAME(8);
+    } else if (s->depth - 1 > 24) {
+        return fail(PTGPU_E_UNSUPPORTED, "ptgpu_trace_frame_dev: tree depth %d needs more than the 24 LDS stack entries of the all-LDS frame kernels "
+                    "(PTGPU_FRAME_NLDS / PTGPU_FRAME_TILE_W select them)", s->depth);
     }
-#undef PT_FRAME
+    ptd::launch_trace_frame(c->stream, grid, with_regions, tw, trav, s->d_nrm, c->d_sobol_pairs, c->d_sobol_matrices, *cam, *light, (int)width, (int)height,
+                            tiles_x, d_id, d_t, d_u, d_v, d_shadow_id, c->d_counters, c->d_stack_ovf, ovf_entries);
     HIP_TRY(hipGetLastError());
     return PTGPU_OK;
 }
