@@ -169,5 +169,32 @@ def test_config4_ten_million_triangles_dof_exact(gpu_ctx, oracle):
         gi = s.render_pass(prm, cam, lights)
         ci, _ = oracle.render_pass(sd, prm, cam, lights, nthreads=8)
         assert ci[..., :3].max() > 0 and np.array_equal(_bits(gi), _bits(ci)), "10 M-triangle DoF render differs"
+        # configs[4] as written names 8 GPUs: the 1080p depth-of-field frame dealt over 8 ranks by 32x32 tiles (here the 8 shares rendered
+        # one after the other on this GPU, each packed into its slice as rank r would), gathered, against the same frame from one rank
+        W, H, world = 1920, 1080, 8
+        cam, lights = scene.tetra_cloud_view(W, H)
+        prm = scene.make_params(width=W, height=H, bounces=-1, num_aa_rays=2, sobol_block=True, depth_of_field=True, aperture=0.01,
+                                focal_distance=1.2, pass_seed=7)
+        nbytes = W * H * 16
+        sf = capi.tiles_slice_floats(W, H, world)
+        acc, full, slices, one = gpu_ctx.malloc(nbytes), gpu_ctx.malloc(nbytes), gpu_ctx.malloc(sf * 4 * world), gpu_ctx.malloc(capi.tiles_slice_floats(W, H, 1) * 4)
+        try:
+            for r in range(world):
+                capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, acc, 0, nbytes))
+                s.render_pass_dev(prm, cam, lights, acc, block_begin=r, block_end=-1, block_stride=world)
+                assert gpu_ctx.spill_status()["dropped"] == 0
+                gpu_ctx.tiles_pack_dev(W, H, world, r, acc, slices + r * sf * 4)
+            gpu_ctx.tiles_unpack_dev(W, H, world, world - 1, slices, acc)  # the last rank's buffer still holds its own tiles
+            capi._check(gpu_ctx.lib.ptgpu_memset(gpu_ctx.handle, full, 0, nbytes))
+            s.render_pass_dev(prm, cam, lights, full)
+            gpu_ctx.tiles_pack_dev(W, H, 1, 0, full, one)
+            gpu_ctx.tiles_unpack_dev(W, H, 1, 0, one, full)
+            gpu_ctx.sync()
+            a, f = gpu_ctx.d2h(acc, (H, W, 4), np.float32), gpu_ctx.d2h(full, (H, W, 4), np.float32)
+        finally:
+            for b in (acc, full, slices, one):
+                gpu_ctx.free(b)
+        assert float(f[..., 3].astype(np.float64).sum()) == float(W * H) and f[..., :3].max() > 0
+        assert np.array_equal(_bits(a), _bits(f)), "8-way sharded frame differs from the one-rank frame in %d words" % int((_bits(a) != _bits(f)).sum())
     finally:
         s.close()
